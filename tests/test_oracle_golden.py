@@ -1,0 +1,163 @@
+"""CPU: the oracle (oracle/cpu_ref.py) against the golden vectors that tools/make_goldens.py
+recorded from the real reference (G1-G7)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref as O
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a), torch.as_tensor(b)
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+
+
+@pytest.mark.parametrize("case", ["A", "B", "C", "D"])
+def test_g1_forward(golden_dir, case):
+    g = load(golden_dir, f"g1_forward_{case}.npz")
+    N, G, H, depth, heads, seed = [int(v) for v in g["cfg"]]
+    p = O.make_params(G, H, depth, seed)
+    # weights are regenerated from the seed: the checksum pins the generator
+    assert abs(float(sum(v.double().abs().sum() for v in p.values())) - float(g["wsum"][0])) < 1e-6 * float(g["wsum"][0])
+    taps = {}
+    with torch.no_grad():
+        eps = O.dit_forward(p, torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), torch.from_numpy(g["y"]),
+                            heads, depth, taps=taps)
+    assert rel(eps, g["eps"]) < 2e-6
+    assert rel(taps["c"], g["c"]) < 2e-6
+    assert rel(taps["h_blk0"], g["h_blk0"]) < 2e-6
+
+
+def test_g2_chunking(golden_dir):
+    g = load(golden_dir, "g1_forward_A.npz")
+    N, G, H, depth, heads, seed = [int(v) for v in g["cfg"]]
+    p = O.make_params(G, H, depth, seed)
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    t = int(g["g2_t"][0])
+    with torch.no_grad():
+        one = O.denoise_chunked(p, x, t, y, N, heads, depth)
+        parts = O.denoise_chunked(p, x, t, y, int(g["g2_batch"][0]), heads, depth)
+    assert rel(one, g["g2_one"]) < 2e-6
+    assert rel(parts, g["g2_chunks"]) < 2e-6
+    assert rel(one, g["g2_chunks"]) > 1e-3      # attention couples the rows of a chunk
+
+
+@pytest.mark.parametrize("sched,T", [("cosine", 20), ("cosine", 1000), ("cosine", 1500), ("linear", 1000), ("quadratic", 1000)])
+def test_g3_tables(golden_dir, sched, T):
+    g = load(golden_dir, "g3_tables.npz")
+    tb = O.make_tables(T, schedule=sched)
+    for n in O.TABLE_NAMES:
+        assert np.array_equal(tb[n].numpy(), g[f"{sched}_{T}_{n}"]), n
+    var = np.array([float(O.variance(tb, t)) for t in range(T)])
+    assert np.array_equal(var, g[f"{sched}_{T}_variance"])
+
+
+def test_g3_known_answers():
+    # SURVEY 8a row S1 (values read off the imported reference)
+    tb = O.make_tables(1000, schedule="cosine")
+    assert abs(float(tb["betas"][0]) - 4.12842237e-05) < 1e-12
+    assert float(tb["betas"][999]) == np.float32(0.999)
+    assert abs(float(tb["sqrt_inv_alphas_cumprod"][999]) - 20291.3027) < 1e-2
+    assert float(tb["posterior_mean_coef2"][0]) == 0.0
+    assert abs(float(tb["posterior_mean_coef1"][0]) - 0.99947232) < 1e-7
+    tb = O.make_tables(1500, schedule="cosine")
+    assert abs(float(tb["sqrt_inv_alphas_cumprod"][1499]) - 30436.9395) < 1e-2
+
+
+def test_g4_step(golden_dir):
+    g = load(golden_dir, "g4_step.npz")
+    tb = O.make_tables(1000, schedule="cosine")
+    for t in (999, 500, 1, 0):
+        x, e, z = (torch.from_numpy(g[f"t{t}_{k}"]) for k in ("x", "eps", "z"))
+        prev, x0 = O.step(tb, e, t, x, z, "noise")
+        assert np.array_equal(prev.numpy(), g[f"t{t}_prev"])
+        assert np.array_equal(x0.numpy(), g[f"t{t}_x0"])
+        prev, _ = O.step(tb, e, t, x, z, "x_start")
+        assert np.array_equal(prev.numpy(), g[f"t{t}_prev_xstart"])
+    out = O.add_noise(tb, torch.from_numpy(g["an_x0"]), torch.from_numpy(g["an_noise"]), torch.from_numpy(g["an_t"]))
+    assert np.array_equal(out.numpy(), g["an_out"])
+    with pytest.raises(NotImplementedError):
+        O.step(tb, e, 3, x, z, "v")
+
+
+def test_g5_sampling(golden_dir):
+    g = load(golden_dir, "g5_sample.npz")
+    N, G, H, depth, heads, seed, T, B = [int(v) for v in g["cfg"]]
+    p = O.make_params(G, H, depth, seed)
+    tb = O.make_tables(T, schedule="cosine")
+    zs = {t: torch.from_numpy(g["z"][i]) for i, t in enumerate(range(T - 1, 0, -1))}
+    rec = {}
+    final = O.sample(p, tb, g["gt"], g["mask"], B, heads, depth, torch.from_numpy(g["x_T"]), lambda t: zs[t], T, T,
+                     record=rec)
+    for i, t in enumerate(range(T - 1, -1, -1)):
+        assert rel(rec["eps"][t], g["eps"][i]) < 1e-5, t
+    assert rel(final, g["final"]) < 1e-5
+    # known genes come back exactly
+    m = g["mask"].astype(bool)
+    assert np.array_equal(final.numpy()[:, m], g["gt"][:, m])
+    part = O.sample(p, tb, g["gt"], g["mask"], B, heads, depth, torch.from_numpy(g["x_T"]), lambda t: zs[t], T, 5)
+    assert rel(part, load(golden_dir, "g5_partial.npz")["final"]) < 1e-5
+
+
+def test_g6_train_steps(golden_dir):
+    g = load(golden_dir, "g6_train.npz")
+    C, G, H, depth, heads, seed, T = [int(v) for v in g["cfg"]]
+    lr = float(g["lr"][0])
+    p = O.make_params(G, H, depth, seed)
+    p0 = {k: v.clone() for k, v in p.items()}
+    tb = O.make_tables(T, schedule="cosine")
+    names = [str(n) for n in g["grad_names"]]
+    state = {}
+    x, xc = torch.from_numpy(g["x"]), torch.from_numpy(g["x_cond"])
+    for i in range(3):
+        loss, gn, raw = O.train_step(p, tb, state, x[i * C:(i + 1) * C], xc[i * C:(i + 1) * C],
+                                     torch.from_numpy(g["noise"][i]), torch.from_numpy(g["timesteps"][i]),
+                                     g["mask"], lr, heads, depth)
+        assert abs(float(loss) - g["loss"][i]) < 2e-6
+        assert abs(float(gn) - g["gnorm"][i]) < 1e-5 * g["gnorm"][i]
+        l2 = np.array([float(raw[n].norm()) for n in names])
+        assert np.allclose(l2, g["grad_l2"][i], rtol=2e-4, atol=1e-7)
+        if i == 0:
+            for k in g.files:
+                if k.startswith("g0/"):
+                    assert rel(raw[k[3:]], g[k]) < 2e-5, k
+    for k in g.files:
+        if k.startswith("post/"):
+            tol = 5e-5 if k.endswith("qkv.bias") else 1e-5   # Adam normalises rounding noise where grad ~ 0 (k-bias)
+            assert rel(p[k[5:]], g[k]) < tol, k
+    d = np.array([float((p[n] - p0[n]).double().norm()) for n in names])
+    assert np.allclose(d, g["delta_l2"], rtol=1e-3, atol=1e-7)
+    assert torch.equal(p["condi_emb.weight"], p0["condi_emb.weight"])
+
+
+def test_g7_ddp_semantics(golden_dir):
+    g6 = load(golden_dir, "g6_train.npz")
+    g = load(golden_dir, "g7_ddp.npz")
+    C, G, H, depth, heads, seed, T = [int(v) for v in g6["cfg"]]
+    p = O.make_params(G, H, depth, seed)
+    tb = O.make_tables(T, schedule="cosine")
+    x, xc = torch.from_numpy(g6["x"]), torch.from_numpy(g6["x_cond"])
+    shards = [(x[i * C:(i + 1) * C], xc[i * C:(i + 1) * C], torch.from_numpy(g6["noise"][i]),
+               torch.from_numpy(g6["timesteps"][i])) for i in range(2)]
+    _, gn, _ = O.ddp_train_step(p, tb, {}, shards, g6["mask"], float(g6["lr"][0]), heads, depth)
+    assert abs(float(gn) - g["gnorm"][0]) < 1e-5 * g["gnorm"][0]
+    for k in g.files:
+        if k.startswith("post/"):
+            tol = 5e-5 if k.endswith("qkv.bias") else 1e-5
+            assert rel(p[k[5:]], g[k]) < tol, k
+
+
+def test_synthetic_data_contract():
+    x = O.synth_expression(300, 64, 0)
+    assert x.dtype == np.float32 and x.min() >= 0 and np.allclose(x.max(1)[x.max(1) > 0], 1.0)
+    m = O.kfold_mask(64, 0)
+    assert m.sum() == 64 - 13 and set(np.unique(m)) == {0.0, 1.0}
+    # the 5 folds partition the genes
+    tot = sum((1 - O.kfold_mask(64, f)) for f in range(5))
+    assert np.array_equal(tot, np.ones(64))
