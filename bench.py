@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- imputed spots/sec of 1000-step masked-DDPM sampling (BASELINE.json metric) on MI355X.
+
+A "step" is ONE reverse-diffusion step (denoiser forward over every chunk + fused DDPM update + known-gene splice +
+timestep advance = one replay of the captured hipGraph) over this rank's whole synthetic spot matrix, resident in
+HBM.  Workload = BASELINE.json configs[1]: 20 000 spots x 1000 genes, hidden 1024, depth 6, 16 heads, chunks of 512
+(the reference batch size), cosine schedule T=1000.   value = spots / (1000 * seconds-per-step), aggregate over ranks.
+Per-step cost does not depend on t, so K timed steps stand for the 1000-step run (stated in `config`).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--rows R]
+N>1: launched by torch.distributed.run, one rank per GPU; spots are sharded chunk-aligned over ranks with no
+collective in the loop (weak scaling: every rank holds --rows spots).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+G, H, DEPTH, HEADS, BATCH, T = 1000, 1024, 6, 16, 512, 1000
+PEAK = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
+
+
+def build_model(dtype, device):
+    from stdiff_amd.model.stDiff_model import DiT_stDiff
+    torch.manual_seed(1202)
+    m = DiT_stDiff(input_size=G, hidden_size=H, depth=DEPTH, dit_type='dit', num_heads=HEADS, classes=6,
+                   mlp_ratio=4.0, compute_dtype=dtype)
+    with torch.no_grad():   # a fresh model outputs exactly 0 (zero-init adaLN/out): re-randomise those
+        for lin in [b.adaLN_modulation[-1] for b in m.blks] + [m.out_layer.adaLN_modulation[-1], m.out_layer.linear]:
+            lin.weight.normal_(0, 0.02)
+            lin.bias.normal_(0, 0.02)
+    return m.to(device).eval()
+
+
+def flops_per_row(chunk):
+    """useful work per row per reverse step: 4GH + 220H^2 + 24*C*H"""
+    return 4 * G * H + 220 * H * H + 24 * chunk * H
+
+
+def gemm_launches(eng, ws):
+    """(M, N, K, closure) of every dense-contraction launch of one denoiser forward, in order."""
+    from stdiff_amd import _lib as L
+    from stdiff_amd import ops
+    pw = eng.pw
+    R = ws.R
+    out = []
+
+    def add(A, W, b, o, **kw):
+        out.append((R, W.shape[0], W.shape[1], lambda: ops.gemm(A, W, b, out=o, **kw)))
+    add(ws.xp, pw.w["in_layer.0.weight"], pw.b("in_layer.0.bias"), ws.h)
+    for k in range(pw.depth):
+        p = f"blks.{k}."
+        add(ws.s, pw.w[p + "adaLN_modulation.1.weight"], pw.b(p + "adaLN_modulation.1.bias"), ws.mod)
+        add(ws.xn, pw.w[p + "attn.qkv.weight"], pw.b(p + "attn.qkv.bias"), ws.qkv)
+        add(ws.o, pw.w[p + "attn.proj.weight"], pw.b(p + "attn.proj.bias"), ws.h, epi=L.EPI_GATE_RES,
+            gate=ws.mod[:, 2 * H:3 * H], res=ws.h)
+        add(ws.xn, pw.w[p + "mlp.fc1.weight"], pw.b(p + "mlp.fc1.bias"), ws.u, epi=L.EPI_GELU)
+        add(ws.u, pw.w[p + "mlp.fc2.weight"], pw.b(p + "mlp.fc2.bias"), ws.h, epi=L.EPI_GATE_RES,
+            gate=ws.mod[:, 5 * H:6 * H], res=ws.h)
+    add(ws.s, pw.w["out_layer.adaLN_modulation.1.weight"], pw.b("out_layer.adaLN_modulation.1.bias"), ws.fmod)
+    add(ws.xn, pw.w["out_layer.linear.weight"], pw.b("out_layer.linear.bias"), ws.eps)
+    return out
+
+
+def measure_gemm_roofline(eng, ws, dtype, reps=3):
+    """Average launch duration of the dominant kernel (gemm_nt_kernel) with HIP events on the launch stream, over the
+    33 launches of one forward; achieved = algorithmic FLOPs (2MNK) / time."""
+    launches = gemm_launches(eng, ws)
+    flops = sum(2.0 * m * n * k for m, n, k, _ in launches)
+    for _, _, _, f in launches:
+        f()
+    torch.cuda.synchronize()
+    total_ms = 0.0
+    for _ in range(reps):
+        evs = []
+        for _, _, _, f in launches:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            f()
+            b.record()
+            evs.append((a, b))
+        torch.cuda.synchronize()
+        total_ms += sum(a.elapsed_time(b) for a, b in evs)
+    avg_ms = total_ms / (reps * len(launches))
+    achieved = flops / len(launches) / (avg_ms * 1e-3) / 1e12
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "gemm_traffic.json")      # PMC-derived HBM bytes per launch, if collected
+    if os.path.isfile(tfile):
+        traffic = json.load(open(tfile)).get(dtype)
+    return {"bound": "mfma", "kernel": "gemm_nt_kernel<%s>" % dtype, "achieved": round(achieved, 1),
+            "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK[dtype], 4), "traffic": traffic,
+            "launches_per_step": len(launches), "avg_launch_us": round(avg_ms * 1e3, 1),
+            "flops_per_launch": flops / len(launches)}
+
+
+def cpu_baseline(rows_chunks=2, steps=2):
+    """The oracle (eager PyTorch fp32 restatement of the reference, oracle/cpu_ref.py) on the host cores, on a bounded
+    sample of the same workload: `rows_chunks` chunks of 512 spots x 1000 genes, `steps` reverse steps."""
+    from oracle import cpu_ref as O
+    n = rows_chunks * BATCH
+    p = O.make_params(G, H, DEPTH, seed=1)
+    tb = O.make_tables(T, schedule="cosine")
+    mask = O.kfold_mask(G, 0)
+    gt = torch.from_numpy((O.synth_expression(n, G, 1) * mask) * 2 - 1)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, G, generator=g)
+    m = torch.from_numpy(mask)
+    x = x * (1 - m) + gt * m
+    with torch.no_grad():
+        O.denoise_chunked(p, x[:64], T - 1, gt[:64], 64, HEADS, DEPTH)      # warm the thread pool
+        t0 = time.perf_counter()
+        for i in range(steps):
+            t = T - 1 - i
+            eps = O.denoise_chunked(p, x, t, gt, BATCH, HEADS, DEPTH)
+            x, _ = O.step(tb, eps, t, x, torch.randn(n, G, generator=g))
+            x = x * (1.0 - m) + m * gt
+        dt = (time.perf_counter() - t0) / steps
+    return {"value": round(n / (1000 * dt), 3), "unit": "spots/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} reverse steps of {n} spots x {G} genes (hidden {H}, chunks of {BATCH}), "
+                      f"{dt:.2f} s/step, extrapolated to 1000 steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--rows", type=int, default=20000, help="spots per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+
+    from stdiff_amd import synth as O         # synthetic inputs (the oracle is imported by cpu_baseline() only)
+    from stdiff_amd import engine as E
+    from stdiff_amd.model.stDiff_scheduler import NoiseScheduler
+
+    model = build_model(args.dtype, dev)
+    eng = model.engine()
+    R = args.rows
+    lens = [min(BATCH, R - i) for i in range(0, R, BATCH)]
+    mask_np = O.kfold_mask(G, 0)
+    st = O.synth_expression(R, G, seed=1 + rank)
+    gt = torch.from_numpy((st * mask_np) * 2 - 1).to(dev)
+    mask = torch.from_numpy(mask_np).to(dev)
+    sched = NoiseScheduler(T, beta_schedule="cosine")
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        smp = E.ReverseSampler(eng, sched, lens, gt, gt, mask, seed=1234, row_offset=rank * R,
+                               use_graph=not args.no_graph)
+        smp.init()
+        ts = list(range(T))[::-1]
+        left = [0]
+
+        def advance(n):          # n reverse steps; wraps to t = T-1 when the schedule is exhausted (timing only)
+            while n > 0:
+                if left[0] == 0:
+                    smp.run(ts[:1])
+                    left[0], n = T - 1, n - 1
+                k = min(n, left[0])
+                if k:
+                    smp.run_more(k)
+                left[0], n = left[0] - k, n - k
+        advance(1)               # setup: hipGraph capture + first replay (untimed)
+        advance(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        advance(args.steps)
+        barrier()
+        dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert bool(torch.isfinite(smp.x).all()), "non-finite sample state"
+    ms_per_step = dt / args.steps * 1e3
+    value = world * R / (T * ms_per_step * 1e-3)
+    step_flops = sum(n * flops_per_row(n) for n in lens)
+
+    rec = {
+        "metric": "imputed spots/sec (1000-step DDPM sampling)", "value": round(value, 2), "unit": "spots/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: {R} spots x {G} genes per GPU, hidden {H}, depth {DEPTH}, "
+                               f"{HEADS} heads, chunks of {BATCH}, cosine T={T}; value = spots / (1000 x measured "
+                               f"seconds per reverse step)", "parallelism": f"spot-sharded x{world}, no collective",
+                   "hipgraph": not args.no_graph, "noise": "in-kernel Philox4x32-10"},
+        "step_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12, 1),
+    }
+    if rank == 0:
+        with torch.no_grad():
+            rec["roofline"] = measure_gemm_roofline(eng, smp.ws, args.dtype)
+        rec["roofline"]["whole_step_frac"] = round(rec["step_tflops"] / PEAK[args.dtype], 4)
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(rec), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

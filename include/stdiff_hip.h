@@ -1,0 +1,214 @@
+/* libstdiff_hip.so -- C ABI of the MI355X (gfx950) stDiff hot path.
+ *
+ * The reference (fdu-wangfeilab/stDiff) has no FFI: its hot path is eager PyTorch behind four
+ * Python callables (DiT_stDiff, NoiseScheduler, normal_train_stDiff, sample_stDiff).  Each entry
+ * point below names the reference lines whose arithmetic it replaces.  The Python package
+ * stdiff_amd/ keeps the reference signatures and calls these through ctypes with raw device
+ * pointers (torch owns all memory) and the caller's hipStream_t.
+ *
+ * Conventions
+ *   - every function returns int: 0 ok, <0 STDIFF_ERR_* (bad argument), >0 a hipError_t;
+ *     nothing throws, nothing aborts, nothing allocates device memory unless it says so;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no internal threads,
+ *     no host synchronisation, so every entry point may be stream-captured into a hipGraph
+ *     (stdiff_graph_*);
+ *   - matrices are row-major with an explicit leading dimension in ELEMENTS;
+ *   - dtype: STDIFF_F32 (exact-fp32 MFMA path) or STDIFF_BF16 (bf16 MFMA, fp32 accumulate).
+ */
+#ifndef STDIFF_HIP_H
+#define STDIFF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STDIFF_ABI_VERSION 1
+
+enum { STDIFF_F32 = 0, STDIFF_BF16 = 1 };
+
+enum {
+    STDIFF_OK = 0,
+    STDIFF_ERR_ARG = -1,      /* null pointer / negative size / bad enum */
+    STDIFF_ERR_SHAPE = -2,    /* shape not supported by the kernels (see each function) */
+    STDIFF_ERR_ALIGN = -3,    /* pointer or leading dimension not 16-byte aligned */
+    STDIFF_ERR_STATE = -4     /* handle misuse (graph not captured, ...) */
+};
+
+/* GEMM epilogues: v = sum_k A[m,k] W[n,k] + bias[n] */
+enum {
+    STDIFF_EPI_BIAS = 0,      /* C = v                                   (nn.Linear) */
+    STDIFF_EPI_SILU = 1,      /* C = silu(v)                             (time MLP, stDiff_model.py:53-57) */
+    STDIFF_EPI_GELU = 2,      /* C = gelu_erf(v)                         (timm Mlp fc1+act, stDiff_model.py:100-103) */
+    STDIFF_EPI_GATE_RES = 3,  /* C = res[m,n] + gate[m,n] * v  (fp32 C)  (gated residual, stDiff_model.py:114,116) */
+    STDIFF_EPI_ADD = 4,       /* C = v + res[m,n]                        (c = t + y, stDiff_model.py:237) */
+    STDIFF_EPI_GELU_SAVE = 5, /* C = gelu_erf(v), C2 = v                 (training: keep the pre-activation) */
+    STDIFF_EPI_ACCUM = 6      /* C = C + v  (fp32 C)                      (gradient accumulation) */
+};
+
+int stdiff_abi_version(void);
+const char* stdiff_error_string(int status);
+
+/* ---------------------------------------------------------------- dense contractions (MFMA)
+ * C[M,N] = epi(A[M,K] . W[N,K]^T + bias): the nn.Linear layers of stDiff_model.py
+ * (:18,20 qkv/proj; :54,56 time MLP; :107,132 adaLN; :128 out; :177,180 in/cond; timm Mlp fc1/fc2).
+ * A and W share a_dtype; K % 64 == 0 (bf16) or K % 16 == 0 (f32); lda/ldw multiples of 8 (bf16) / 4 (f32)
+ * elements and A/W 16-byte aligned; M, N arbitrary. gate has a_dtype, res is fp32. */
+typedef struct {
+    int M, N, K;
+    const void* A; int lda; int a_dtype;
+    const void* W; int ldw;
+    const float* bias;
+    void* C; int ldc; int c_dtype;
+    int epi;
+    const void* gate; int ldgate;
+    const float* res; int ldres;
+    void* C2; int ldc2;
+} stdiff_gemm_args;
+int stdiff_gemm(const stdiff_gemm_args* a, void* stream);
+
+/* out[C,R] = in[R,C]^T (same dtype); used to turn the TN/NN backward contractions into NT GEMMs. */
+int stdiff_transpose(const void* in, int ld_in, void* out, int ld_out, int rows, int cols, int dtype, void* stream);
+
+/* ---------------------------------------------------------------- cell-axis attention
+ * Attention2.forward core (stDiff_model.py:25-34): per chunk (consecutive rows cu_rows[c]..cu_rows[c+1]) and
+ * head, softmax(q k^T d^-0.5) v over the CELLS of that chunk; never materialises [h,C,C].
+ * qkv: [R, 3H] (ld = ldqkv) in the nn.Linear column order [q|k|v], each heads x d; out: [R, H].
+ * d = H/heads must be 32, 64 or 128.  lse (optional, fp32 [R, heads]) receives log2-sum-exp rows for backward. */
+int stdiff_attention_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, const int32_t* cu_rows,
+                         int n_chunks, int max_chunk_rows, int heads, int head_dim, int dtype, void* stream);
+
+/* backward of the above: dqkv[R,3H] from dout[R,H], recomputing P from qkv and lse.
+ * delta (fp32 [R, heads]) is scratch supplied by the caller. */
+int stdiff_attention_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const void* dout, int lddo,
+                         const float* lse, float* delta, void* dqkv, int lddqkv, const int32_t* cu_rows, int n_chunks,
+                         int max_chunk_rows, int heads, int head_dim, int dtype, void* stream);
+
+/* ---------------------------------------------------------------- bandwidth-bound fused kernels
+ * y = LayerNorm(x; eps 1e-6, no affine, biased var) * (1 + scale) + shift   (modulate, stDiff_model.py:41-44,96,99,126)
+ * x fp32 [R,H]; shift/scale rows of the adaLN output (dtype mod_dtype, leading dim ldmod); y [R,H] of out_dtype.
+ * Optionally writes mean/rstd (fp32 [R]) for backward. */
+int stdiff_ln_modulate(const float* x, int ldx, const void* shift, const void* scale, int ldmod, int mod_dtype,
+                       void* y, int ldy, int out_dtype, float* mean, float* rstd, int R, int H, void* stream);
+
+/* s[r,:] = silu(c[r,:])  with  c[r,:] = temb[*t_index, :] + ycond[r,:]  when temb != NULL (sampling: every row of a
+ * reverse step shares t, model/sample.py:11), else c = ycond (training: c precomputed).   (nn.SiLU of
+ * adaLN_modulation, stDiff_model.py:105-108,130-133; c = t + y, :237) */
+int stdiff_silu_cond(const float* temb, const int32_t* t_index, const float* ycond, int ldy, void* s, int lds,
+                     int out_dtype, int R, int H, void* stream);
+
+/* sinusoidal timestep embedding (stDiff_model.py:61-80): t int64 [R] -> [R,256] of out_dtype, [cos(t f) | sin(t f)].
+ * freqs: device fp32 [128] = exp(-ln(1e4) k/128), computed by the caller with the reference's fp32 op sequence. */
+int stdiff_timestep_embedding(const int64_t* t, const float* freqs, void* out, int ldo, int out_dtype, int R,
+                              void* stream);
+
+/* dst[R, ldd] (dtype) = src[R, C] fp32, columns C..Cpad-1 zero-filled (operand packing for the MFMA kernels). */
+int stdiff_pack_rows(const float* src, int lds, void* dst, int ldd, int dtype, int R, int C, int Cpad, void* stream);
+
+/* ---------------------------------------------------------------- diffusion arithmetic
+ * One reverse step + known-gene splice, fused (NoiseScheduler.step, stDiff_scheduler.py:103-139 ->
+ * reconstruct_x0 :68-78, q_posterior :80-90, get_variance :92-100; splice model/sample.py:94-95):
+ *   x0 = clamp(a*x - b*eps, -1, 1)   (pred_type 0 'noise')   |   x0 = eps   (pred_type 1 'x_start')
+ *   x  = (c1*x0 + c2*x + sigma*z) * (1-mask) + mask*gt       with (a,b,c1,c2,sigma) = coef[t*5 .. t*5+4]
+ * t = *t_dev (device int32, so a captured graph can be replayed) ; z = z_base + z_index*R*G when z_base != NULL
+ * (z_index = t_first - t), otherwise Philox4x32-10 + Box-Muller keyed by (seed, t, global element index).
+ * Also refreshes xp (the [R,Gp] MFMA operand copy of x) when xp != NULL. Arithmetic order equals the reference's
+ * (no FMA contraction) so fp32 results are bit-identical to it. */
+typedef struct {
+    float* x; const float* eps; const float* gt; const float* mask; const float* coef;
+    const int32_t* t_dev; int t_first;
+    const float* z_base; uint64_t seed; int64_t row_offset;   /* row_offset: global index of row 0 (sharded sampling) */
+    void* xp; int ldxp; int xp_dtype;
+    int R, G, pred_type;
+} stdiff_step_args;
+int stdiff_ddpm_step(const stdiff_step_args* a, void* stream);
+/* *t_dev -= 1 (one thread; closes a captured reverse step). */
+int stdiff_advance_timestep(int32_t* t_dev, void* stream);
+
+/* x_T init of sample_stDiff (model/sample.py:56-60): x = z*(1-mask) + gt*mask, z injected or Philox. */
+int stdiff_init_sample(float* x, const float* z, uint64_t seed, int64_t row_offset, const float* gt, const float* mask,
+                       void* xp, int ldxp, int xp_dtype, int R, int G, void* stream);
+
+/* forward diffusion + train splice (stDiff_scheduler.py:141-148; stDiff_train.py:65-70):
+ * x_noisy = (sa[t_r]*x + sb[t_r]*noise)*(1-mask) + x*mask, written as fp32 and/or as the packed operand xp. */
+int stdiff_add_noise_splice(const float* x, const float* noise, const int64_t* t, const float* sqrt_ac,
+                            const float* sqrt_1mac, const float* mask, float* x_noisy, void* xp, int ldxp, int xp_dtype,
+                            int R, int G, void* stream);
+
+/* masked MSE (stDiff_train.py:75): loss = mean_{R*G}((noise*(1-m) - pred*(1-m))^2) accumulated into *loss (caller
+ * zeroes it) and dpred = 2*(1-m)^2*(pred-noise)/(R*G) * grad_scale, as fp32 and/or the packed operand dp. */
+int stdiff_masked_mse(const float* pred, const float* noise, const float* mask, float* loss, float* dpred, void* dp,
+                      int lddp, int dp_dtype, float grad_scale, int R, int G, void* stream);
+
+/* ---------------------------------------------------------------- backward helpers (training)
+ * d(LN-modulate): given dy [R,H] (dtype), x, mean, rstd, scale, shift-layout as in forward:
+ *   dx[R,H] (fp32, accumulated into dx when accumulate != 0), dshift = dy, dscale = dy * xhat  (dtype, into dmod cols). */
+int stdiff_ln_modulate_bwd(const void* dy, int lddy, int dtype, const float* x, int ldx, const float* mean,
+                           const float* rstd, const void* scale, int ldmod, float* dx, int lddx, int accumulate,
+                           void* dshift, void* dscale, int lddmod, int R, int H, void* stream);
+/* gated residual backward: dbranch = dh*gate (dtype), dgate = dh*branch (dtype) ; dh fp32 */
+int stdiff_gate_bwd(const float* dh, int lddh, const void* gate, int ldgate, const void* branch, int ldbr,
+                    void* dbranch, int lddb, void* dgate, int lddg, int dtype, int R, int H, void* stream);
+/* du = dg * gelu'(u_pre)  (erf GELU) */
+int stdiff_gelu_bwd(const void* dg, const void* u_pre, void* du, int ld, int dtype, int R, int C, void* stream);
+/* dc += ds * silu'(c);  ds in dtype, c/dc fp32 */
+int stdiff_silu_bwd(const void* ds, int ldds, int dtype, const float* c, float* dc, int ldc, int accumulate, int R,
+                    int H, void* stream);
+/* db[n] (+)= sum_m dY[m,n]   (bias gradients) */
+int stdiff_colsum(const void* dY, int ld, int dtype, float* db, int accumulate, int R, int C, void* stream);
+
+/* ---------------------------------------------------------------- optimizer (stDiff_train.py:47,78-80)
+ * Multi-tensor: tensors are described by device arrays of pointers / sizes built once by the caller. */
+/* sumsq[0] += sum over all tensors of g^2 (caller zeroes it). */
+int stdiff_grad_sumsq(const float* const* grads, const int64_t* sizes, int n_tensors, float* sumsq, void* stream);
+/* clip_grad_norm_(1.0) + AdamW(weight_decay) in one pass: coef = min(1, max_norm/(sqrt(*sumsq)*inv_world+1e-6));
+ * g *= inv_world*coef; m,v,p update with bias correction for `step` (1-based). Also refreshes the bf16 operand
+ * copies p16[i] when non-null. */
+typedef struct {
+    float* const* params; const float* const* grads; float* const* exp_avg; float* const* exp_avg_sq;
+    void* const* p16; const int64_t* sizes; int n_tensors;
+    const float* sumsq; float max_norm; float inv_world;
+    float lr, beta1, beta2, eps, weight_decay; int step;
+} stdiff_adamw_args;
+int stdiff_clip_adamw(const stdiff_adamw_args* a, void* stream);
+
+/* ---------------------------------------------------------------- whole-denoiser forward (inference)
+ * DiT_stDiff.forward after the conditioning (stDiff_model.py:240-243): in_layer, depth x DiTblock, FinalLayer,
+ * on R rows split into chunks (attention is per chunk).  Inputs: xp = packed x [R,Gp], s = silu(c) [R,H].
+ * All buffers are caller-owned (torch).  Enqueues ~8 kernels per block on `stream`. */
+typedef struct {
+    const void* qkv_w; const float* qkv_b;
+    const void* proj_w; const float* proj_b;
+    const void* fc1_w; const float* fc1_b;
+    const void* fc2_w; const float* fc2_b;
+    const void* ada_w; const float* ada_b;
+} stdiff_block_weights;
+typedef struct {
+    int dtype, G, Gp, H, heads, depth;
+    const void* in_w; const float* in_b;       /* [H,Gp] */
+    const void* out_w; const float* out_b;     /* [G,H]  */
+    const void* fada_w; const float* fada_b;   /* [2H,H] */
+    const stdiff_block_weights* blocks;        /* host array [depth] */
+} stdiff_dit_weights;
+typedef struct {
+    int R, n_chunks, max_chunk_rows;
+    const int32_t* cu_rows;                    /* device int32 [n_chunks+1] */
+    float* h;                                  /* [R,H]  residual stream */
+    void* mod; void* xn; void* qkv; void* o; void* u; void* fmod;   /* [R,6H] [R,H] [R,3H] [R,H] [R,4H] [R,2H] */
+} stdiff_dit_workspace;
+int stdiff_dit_forward(const stdiff_dit_weights* w, const stdiff_dit_workspace* ws, const void* xp, const void* s,
+                       float* eps, int ldeps, void* stream);
+
+/* ---------------------------------------------------------------- hipGraph capture of a reverse step
+ * begin/end bracket any sequence of the calls above on `stream`; launch replays it (model/sample.py:67-95 loop body
+ * captured once, replayed num_step times with t read from device memory). */
+int stdiff_graph_begin(void* stream);
+int stdiff_graph_end(void* stream, void** graph_exec_out);
+int stdiff_graph_launch(void* graph_exec, void* stream);
+int stdiff_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

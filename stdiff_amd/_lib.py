@@ -1,0 +1,141 @@
+"""ctypes binding of libstdiff_hip.so (include/stdiff_hip.h).  Fails loudly if the library is missing:
+there is no CPU or eager-PyTorch fallback anywhere in this package."""
+import ctypes as C
+import os
+
+import torch
+
+F32, BF16 = 0, 1
+EPI_BIAS, EPI_SILU, EPI_GELU, EPI_GATE_RES, EPI_ADD, EPI_GELU_SAVE, EPI_ACCUM = range(7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstdiff_hip.so")
+
+vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("M", i32), ("N", i32), ("K", i32),
+                ("A", vp), ("lda", i32), ("a_dtype", i32),
+                ("W", vp), ("ldw", i32),
+                ("bias", vp),
+                ("C", vp), ("ldc", i32), ("c_dtype", i32),
+                ("epi", i32),
+                ("gate", vp), ("ldgate", i32),
+                ("res", vp), ("ldres", i32),
+                ("C2", vp), ("ldc2", i32)]
+
+
+class StepArgs(C.Structure):
+    _fields_ = [("x", vp), ("eps", vp), ("gt", vp), ("mask", vp), ("coef", vp),
+                ("t_dev", vp), ("t_first", i32),
+                ("z_base", vp), ("seed", u64), ("row_offset", i64),
+                ("xp", vp), ("ldxp", i32), ("xp_dtype", i32),
+                ("R", i32), ("G", i32), ("pred_type", i32)]
+
+
+class BlockWeights(C.Structure):
+    _fields_ = [(n, vp) for n in ("qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
+                                  "ada_w", "ada_b")]
+
+
+class DitWeights(C.Structure):
+    _fields_ = [("dtype", i32), ("G", i32), ("Gp", i32), ("H", i32), ("heads", i32), ("depth", i32),
+                ("in_w", vp), ("in_b", vp), ("out_w", vp), ("out_b", vp), ("fada_w", vp), ("fada_b", vp),
+                ("blocks", C.POINTER(BlockWeights))]
+
+
+class DitWorkspace(C.Structure):
+    _fields_ = [("R", i32), ("n_chunks", i32), ("max_chunk_rows", i32), ("cu_rows", vp),
+                ("h", vp), ("mod", vp), ("xn", vp), ("qkv", vp), ("o", vp), ("u", vp), ("fmod", vp)]
+
+
+class AdamWArgs(C.Structure):
+    _fields_ = [("params", vp), ("grads", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("p16", vp), ("sizes", vp),
+                ("n_tensors", i32), ("sumsq", vp), ("max_norm", f32), ("inv_world", f32),
+                ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("step", i32)]
+
+
+_SIGS = {
+    "stdiff_abi_version": (i32, []),
+    "stdiff_error_string": (C.c_char_p, [i32]),
+    "stdiff_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "stdiff_transpose": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
+    "stdiff_attention_fwd": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
+    "stdiff_ln_modulate": (i32, [vp, i32, vp, vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, vp]),
+    "stdiff_silu_cond": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]),
+    "stdiff_timestep_embedding": (i32, [vp, vp, vp, i32, i32, i32, vp]),
+    "stdiff_pack_rows": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "stdiff_ddpm_step": (i32, [C.POINTER(StepArgs), vp]),
+    "stdiff_advance_timestep": (i32, [vp, vp]),
+    "stdiff_init_sample": (i32, [vp, vp, u64, i64, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "stdiff_add_noise_splice": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "stdiff_masked_mse": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp]),
+    "stdiff_dit_forward": (i32, [C.POINTER(DitWeights), C.POINTER(DitWorkspace), vp, vp, vp, i32, vp]),
+    "stdiff_graph_begin": (i32, [vp]),
+    "stdiff_graph_end": (i32, [vp, C.POINTER(vp)]),
+    "stdiff_graph_launch": (i32, [vp, vp]),
+    "stdiff_graph_destroy": (i32, [vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (raises if it was not built: run `python -c 'import __graft_entry__ as g; g.build()'`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension was not built (make -C stdiff_amd/csrc). "
+                "stdiff_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        missing = [name for name in _SIGS if not hasattr(L, name)]
+        if missing:
+            raise RuntimeError(f"libstdiff_hip.so lacks symbols declared in include/stdiff_hip.h: {missing}")
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        if L.stdiff_abi_version() != 1:
+            raise RuntimeError("libstdiff_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+class StdiffError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().stdiff_error_string(rc).decode()
+        if rc in (-1, -2, -3):
+            raise ValueError(f"stdiff_hip: {msg} (status {rc})")
+        raise StdiffError(f"stdiff_hip: {msg} (status {rc})")
+
+
+def ptr(t):
+    """Raw device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt_of(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def torch_dtype(dt):
+    return torch.bfloat16 if dt == BF16 else torch.float32
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("stdiff_amd runs on MI355X only: got a CPU tensor (no CPU fallback exists)")

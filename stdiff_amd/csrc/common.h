@@ -1,0 +1,76 @@
+// Shared device helpers for the stDiff CDNA4 (gfx950) kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/stdiff_hip.h"
+
+typedef unsigned short bf16_t;  // storage type of a bf16 element
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define WAVE 64
+
+// Status codes follow include/stdiff_hip.h: 0 ok, <0 bad argument, >0 hipError_t.
+#define STDIFF_CHECK_ARG(cond) \
+    do {                       \
+        if (!(cond)) return STDIFF_ERR_ARG; \
+    } while (0)
+#define STDIFF_LAUNCH_STATUS()                 \
+    do {                                       \
+        hipError_t e__ = hipGetLastError();    \
+        if (e__ != hipSuccess) return (int)e__; \
+    } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }  // RNE, NaN-safe
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// 4 consecutive elements <-> 4 floats (16-B access for f32, 8-B for bf16). p must be aligned to that.
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 ld4(const bf16_t* p) {
+    u32x2 r = *(const u32x2*)p;
+    f32x4 v;
+    v[0] = __builtin_bit_cast(float, r[0] << 16);
+    v[1] = __builtin_bit_cast(float, r[0] & 0xffff0000u);
+    v[2] = __builtin_bit_cast(float, r[1] << 16);
+    v[3] = __builtin_bit_cast(float, r[1] & 0xffff0000u);
+    return v;
+}
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *(f32x4*)p = v; }
+__device__ __forceinline__ void st4(bf16_t* p, f32x4 v) {
+    u32x2 r;
+    r[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+    r[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    *(u32x2*)p = r;
+}
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float gelu_erf_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline size_t dtype_size(int dt) { return dt == STDIFF_BF16 ? 2 : 4; }

@@ -1,0 +1,180 @@
+// Bandwidth-bound fused kernels of the denoiser: adaLN LayerNorm+modulate, SiLU of the conditioning vector,
+// sinusoidal timestep embedding, operand packing.  One 64-lane wave owns one row; rows live in registers between
+// the two reduction passes, every global access is a 16-byte (fp32) / 8-byte (bf16) vector per lane.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------- LayerNorm + modulate (stDiff_model.py:41-44,96,99,126)
+// NV = float4 vectors per lane: H <= 256*NV.
+template <int NV, typename TM, typename TO>
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, int ldx, const TM* shift,
+                                                          const TM* scale, int ldmod, TO* y, int ldy, float* mean_out,
+                                                          float* rstd_out, int R, int H) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float* xr = x + (size_t)row * ldx;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int c = (i * 64 + lane) * 4;
+        v[i] = c < H ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int c = (i * 64 + lane) * 4;
+        if (c < H) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { float d = v[i][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)H + 1e-6f);
+    if (mean_out && lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    const TM* sh = shift + (size_t)row * ldmod;
+    const TM* sc = scale + (size_t)row * ldmod;
+    TO* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int c = (i * 64 + lane) * 4;
+        if (c < H) {
+            f32x4 a = ld4(sh + c), b = ld4(sc + c), o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * (1.0f + b[j]) + a[j];
+            st4(yr + c, o);
+        }
+    }
+}
+
+template <typename TM, typename TO>
+int launch_ln(const float* x, int ldx, const void* shift, const void* scale, int ldmod, void* y, int ldy, float* mean,
+              float* rstd, int R, int H, hipStream_t st) {
+    dim3 grid(cdiv(R, 4)), block(256);
+#define LN_CASE(NV)                                                                                              \
+    hipLaunchKernelGGL((ln_modulate_kernel<NV, TM, TO>), grid, block, 0, st, x, ldx, (const TM*)shift,           \
+                       (const TM*)scale, ldmod, (TO*)y, ldy, mean, rstd, R, H)
+    if (H <= 256) LN_CASE(1);
+    else if (H <= 512) LN_CASE(2);
+    else if (H <= 1024) LN_CASE(4);
+    else if (H <= 2048) LN_CASE(8);
+    else if (H <= 4096) LN_CASE(16);
+    else return STDIFF_ERR_SHAPE;
+#undef LN_CASE
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}
+
+// ---------------------------------------------------------------- s = silu(temb[t] + ycond)
+template <typename TO>
+__global__ __launch_bounds__(256) void silu_cond_kernel(const float* __restrict__ temb, const int32_t* t_index,
+                                                        const float* __restrict__ ycond, int ldy, TO* s, int lds,
+                                                        int R, int H) {
+    const int hv = H >> 2;
+    const float* te = temb ? temb + (size_t)(*t_index) * H : nullptr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)R * hv;
+         i += (size_t)gridDim.x * blockDim.x) {
+        int r = (int)(i / hv), c = (int)(i % hv) * 4;
+        f32x4 v = *(const f32x4*)(ycond + (size_t)r * ldy + c);
+        if (te) {
+            f32x4 t = *(const f32x4*)(te + c);
+            v += t;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+        st4(s + (size_t)r * lds + c, v);
+    }
+}
+
+// ---------------------------------------------------------------- sinusoidal embedding (stDiff_model.py:61-80)
+template <typename TO>
+__global__ __launch_bounds__(256) void timestep_embedding_kernel(const int64_t* t, const float* freqs, TO* out,
+                                                                 int ldo, int R) {
+    // 256 threads = the 256 output columns of one row: [cos(t f_k) | sin(t f_k)]; f_k = exp(-ln(1e4) k / 128) comes
+    // from the host (computed with the reference's own fp32 op sequence: t*f_k reaches ~1e3 rad, so an ulp of f_k matters)
+    const int col = threadIdx.x, k = col & 127;
+    const float f = freqs[k];
+    for (int r = blockIdx.x; r < R; r += gridDim.x) {
+        float a = (float)t[r] * f;
+        Elem<TO>::st(out + (size_t)r * ldo + col, col < 128 ? cosf(a) : sinf(a));
+    }
+}
+
+template <typename TO>
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ src, int lds, TO* dst, int ldd, int R,
+                                                        int C, int Cpad) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)R * Cpad;
+         i += (size_t)gridDim.x * blockDim.x) {
+        int r = (int)(i / Cpad), c = (int)(i % Cpad);
+        Elem<TO>::st(dst + (size_t)r * ldd + c, c < C ? src[(size_t)r * lds + c] : 0.f);
+    }
+}
+
+inline int ew_grid(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 8); }
+inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" int stdiff_ln_modulate(const float* x, int ldx, const void* shift, const void* scale, int ldmod,
+                                  int mod_dtype, void* y, int ldy, int out_dtype, float* mean, float* rstd, int R,
+                                  int H, void* stream) {
+    STDIFF_CHECK_ARG(x && shift && scale && y && R >= 0 && H > 0);
+    STDIFF_CHECK_ARG((mean == nullptr) == (rstd == nullptr));
+    if (R == 0) return STDIFF_OK;
+    if (H % 4) return STDIFF_ERR_SHAPE;
+    if (ldx % 4 || ldmod % 4 || ldy % 4 || !al16(x) || ((uintptr_t)shift & 7) || ((uintptr_t)scale & 7) ||
+        ((uintptr_t)y & 7))
+        return STDIFF_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const bool mb = mod_dtype == STDIFF_BF16, ob = out_dtype == STDIFF_BF16;
+    if (mb && ob) return launch_ln<bf16_t, bf16_t>(x, ldx, shift, scale, ldmod, y, ldy, mean, rstd, R, H, st);
+    if (!mb && !ob) return launch_ln<float, float>(x, ldx, shift, scale, ldmod, y, ldy, mean, rstd, R, H, st);
+    if (!mb && ob) return launch_ln<float, bf16_t>(x, ldx, shift, scale, ldmod, y, ldy, mean, rstd, R, H, st);
+    return launch_ln<bf16_t, float>(x, ldx, shift, scale, ldmod, y, ldy, mean, rstd, R, H, st);
+}
+
+extern "C" int stdiff_silu_cond(const float* temb, const int32_t* t_index, const float* ycond, int ldy, void* s,
+                                int lds, int out_dtype, int R, int H, void* stream) {
+    STDIFF_CHECK_ARG(ycond && s && R >= 0 && H > 0 && (temb == nullptr || t_index != nullptr));
+    if (R == 0) return STDIFF_OK;
+    if (H % 4) return STDIFF_ERR_SHAPE;
+    if (ldy % 4 || lds % 4 || !al16(ycond) || (temb && !al16(temb)) || ((uintptr_t)s & 7)) return STDIFF_ERR_ALIGN;
+    dim3 grid(ew_grid((size_t)R * H / 4)), block(256);
+    if (out_dtype == STDIFF_BF16)
+        hipLaunchKernelGGL(silu_cond_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, temb, t_index, ycond, ldy,
+                           (bf16_t*)s, lds, R, H);
+    else
+        hipLaunchKernelGGL(silu_cond_kernel<float>, grid, block, 0, (hipStream_t)stream, temb, t_index, ycond, ldy,
+                           (float*)s, lds, R, H);
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}
+
+extern "C" int stdiff_timestep_embedding(const int64_t* t, const float* freqs, void* out, int ldo, int out_dtype, int R,
+                                         void* stream) {
+    STDIFF_CHECK_ARG(t && freqs && out && R >= 0 && ldo >= 256);
+    if (R == 0) return STDIFF_OK;
+    dim3 grid(std::min(R, 4096)), block(256);
+    if (out_dtype == STDIFF_BF16)
+        hipLaunchKernelGGL(timestep_embedding_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, t, freqs, (bf16_t*)out, ldo, R);
+    else
+        hipLaunchKernelGGL(timestep_embedding_kernel<float>, grid, block, 0, (hipStream_t)stream, t, freqs, (float*)out, ldo, R);
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}
+
+extern "C" int stdiff_pack_rows(const float* src, int lds, void* dst, int ldd, int dtype, int R, int C, int Cpad,
+                                void* stream) {
+    STDIFF_CHECK_ARG(src && dst && R >= 0 && C > 0 && Cpad >= C && ldd >= Cpad && lds >= C);
+    if (R == 0) return STDIFF_OK;
+    dim3 grid(ew_grid((size_t)R * Cpad)), block(256);
+    if (dtype == STDIFF_BF16)
+        hipLaunchKernelGGL(pack_rows_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, src, lds, (bf16_t*)dst, ldd, R, C, Cpad);
+    else
+        hipLaunchKernelGGL(pack_rows_kernel<float>, grid, block, 0, (hipStream_t)stream, src, lds, (float*)dst, ldd, R, C, Cpad);
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}

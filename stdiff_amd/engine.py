@@ -1,0 +1,254 @@
+"""Device-side engine behind DiT_stDiff / sample_stDiff: packed MFMA operands, workspaces, the enqueue of one
+denoiser forward and the hipGraph-captured reverse-diffusion step.  All memory is torch-owned; all arithmetic is
+in libstdiff_hip.so."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import ops
+from ._lib import BF16, F32, check, lib, ptr, stream, torch_dtype
+
+DTYPES = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}
+
+
+def parse_dtype(name):
+    if isinstance(name, int):
+        return name
+    try:
+        return DTYPES[str(name).lower()]
+    except KeyError:
+        raise ValueError(f"compute dtype must be 'fp32' or 'bf16', got {name!r}")
+
+
+def sinusoid_freqs(device):
+    """exp(-ln(1e4) * arange(128) / 128) with the reference's fp32 op sequence (stDiff_model.py:73-75)."""
+    f = torch.exp(-math.log(10000) * torch.arange(start=0, end=128, dtype=torch.float32) / 128)
+    return f.to(device)
+
+
+class PackedWeights:
+    """MFMA-operand copies of a DiT_stDiff state dict: weights in the compute dtype ([out, in] rows, the gene axis
+    of in/cond layers zero-padded to a multiple of 64), biases fp32.  `refresh()` re-reads the parameters."""
+
+    def __init__(self, params, G, H, depth, heads, dtype):
+        if H % heads:
+            raise AssertionError("dim should be divisible by num_heads")      # stDiff_model.py:13
+        d = H // heads
+        if H % 64 or d not in (32, 64, 128):
+            raise ValueError(f"hidden_size {H} / num_heads {heads}: the gfx950 kernels need hidden % 64 == 0 and "
+                             f"head_dim in (32, 64, 128)")
+        self.params = params
+        self.G, self.H, self.depth, self.heads, self.dtype = G, H, depth, heads, dtype
+        self.Gp = ops.round_up(G, 64)
+        self.tdt = torch_dtype(dtype)
+        dev = params["in_layer.0.weight"].device
+        self.device = dev
+        self.w = {}
+        for name, p in params.items():
+            if name.endswith(".weight") and name != "condi_emb.weight":
+                kp = self.Gp if name in ("in_layer.0.weight", "cond_layer.0.weight") else p.shape[1]
+                self.w[name] = torch.empty((p.shape[0], kp), device=dev, dtype=self.tdt)
+        self.freqs = sinusoid_freqs(dev)
+        self.refresh()
+        self._build_struct()
+
+    def refresh(self):
+        for name, buf in self.w.items():
+            ops.pack_rows(self.params[name].detach(), buf.shape[1], buf.dtype, out=buf)
+
+    def b(self, name):
+        return self.params[name].detach()
+
+    def _build_struct(self):
+        self.blocks = (L.BlockWeights * self.depth)()
+        for k in range(self.depth):
+            pre = f"blks.{k}."
+            bw = self.blocks[k]
+            for f, n in (("qkv", "attn.qkv"), ("proj", "attn.proj"), ("fc1", "mlp.fc1"), ("fc2", "mlp.fc2"),
+                         ("ada", "adaLN_modulation.1")):
+                setattr(bw, f + "_w", ptr(self.w[pre + n + ".weight"]))
+                setattr(bw, f + "_b", ptr(self.b(pre + n + ".bias")))
+        s = L.DitWeights()
+        s.dtype, s.G, s.Gp, s.H, s.heads, s.depth = self.dtype, self.G, self.Gp, self.H, self.heads, self.depth
+        s.in_w, s.in_b = ptr(self.w["in_layer.0.weight"]), ptr(self.b("in_layer.0.bias"))
+        s.out_w, s.out_b = ptr(self.w["out_layer.linear.weight"]), ptr(self.b("out_layer.linear.bias"))
+        s.fada_w = ptr(self.w["out_layer.adaLN_modulation.1.weight"])
+        s.fada_b = ptr(self.b("out_layer.adaLN_modulation.1.bias"))
+        s.blocks = C.cast(self.blocks, C.POINTER(L.BlockWeights))
+        self.struct = s
+
+
+class Workspace:
+    """Activation buffers for R rows in chunks (chunk = one reference mini-batch; attention never crosses chunks)."""
+
+    def __init__(self, pw, chunk_lens):
+        R = int(sum(chunk_lens))
+        H, dev, tdt = pw.H, pw.device, pw.tdt
+        self.R, self.chunk_lens = R, list(chunk_lens)
+        cu = np.concatenate([[0], np.cumsum(chunk_lens)]).astype(np.int32)
+        self.cu_rows = torch.from_numpy(cu).to(dev)
+        self.h = torch.empty((R, H), device=dev, dtype=torch.float32)
+        self.s = torch.empty((R, H), device=dev, dtype=tdt)
+        self.mod = torch.empty((R, 6 * H), device=dev, dtype=tdt)
+        self.xn = torch.empty((R, H), device=dev, dtype=tdt)
+        self.qkv = torch.empty((R, 3 * H), device=dev, dtype=tdt)
+        self.o = torch.empty((R, H), device=dev, dtype=tdt)
+        self.u = torch.empty((R, 4 * H), device=dev, dtype=tdt)
+        self.fmod = torch.empty((R, 2 * H), device=dev, dtype=tdt)
+        self.xp = torch.zeros((R, pw.Gp), device=dev, dtype=tdt)       # pad columns stay zero
+        self.eps = torch.empty((R, pw.G), device=dev, dtype=torch.float32)
+        s = L.DitWorkspace()
+        s.R, s.n_chunks, s.max_chunk_rows = R, len(chunk_lens), int(max(chunk_lens)) if chunk_lens else 0
+        s.cu_rows = ptr(self.cu_rows)
+        for n in ("h", "mod", "xn", "qkv", "o", "u", "fmod"):
+            setattr(s, n, ptr(getattr(self, n)))
+        self.struct = s
+
+
+class DenoiserEngine:
+    def __init__(self, pw):
+        self.pw = pw
+        self._ws = {}
+
+    def workspace(self, chunk_lens):
+        key = tuple(int(c) for c in chunk_lens)
+        ws = self._ws.get(key)
+        if ws is None:
+            if len(self._ws) > 4:
+                self._ws.clear()
+            ws = self._ws[key] = Workspace(self.pw, key)
+        return ws
+
+    # time_emb(t)  (TimestepEmbedder.forward, stDiff_model.py:82-85) -> fp32 [R,H]
+    def time_embed(self, t):
+        pw = self.pw
+        e = ops.timestep_embedding(t, pw.freqs, out_dtype=pw.tdt)
+        e = ops.gemm(e, pw.w["time_emb.mlp.0.weight"], pw.b("time_emb.mlp.0.bias"), epi=L.EPI_SILU)
+        return ops.gemm(e, pw.w["time_emb.mlp.2.weight"], pw.b("time_emb.mlp.2.bias"), out_dtype=torch.float32)
+
+    # cond_layer(y) (+ temb)  (stDiff_model.py:235-237) -> fp32 [R,H]
+    def cond_embed(self, y, temb=None):
+        pw = self.pw
+        yp = ops.pack_rows(y, pw.Gp, pw.tdt)
+        return ops.gemm(yp, pw.w["cond_layer.0.weight"], pw.b("cond_layer.0.bias"), out_dtype=torch.float32,
+                        epi=L.EPI_ADD if temb is not None else L.EPI_BIAS, res=temb)
+
+    def run(self, ws):
+        """eps = blocks/final(in_layer(ws.xp); ws.s)   (stDiff_model.py:240-243)."""
+        check(lib().stdiff_dit_forward(C.byref(self.pw.struct), C.byref(ws.struct), ptr(ws.xp), ptr(ws.s),
+                                       ptr(ws.eps), ws.eps.stride(0), stream()))
+        return ws.eps
+
+    def forward(self, x, t, y, chunk_lens=None):
+        """DiT_stDiff.forward(x, t, y) (stDiff_model.py:231-243) for inference; returns a fresh fp32 [R,G]."""
+        R = x.shape[0]
+        ws = self.workspace(chunk_lens or [R])
+        ops.pack_rows(x, self.pw.Gp, self.pw.tdt, out=ws.xp)
+        c = self.cond_embed(y, self.time_embed(t))
+        ops.silu_cond(c, out=ws.s)
+        return self.run(ws).clone()
+
+
+def step_coefficients(sched):
+    """[T,5] fp32 (a, b, c1, c2, sigma) per timestep from the scheduler's own tables; sigma = variance**0.5 with
+    get_variance's clip and t==0 -> 0 (stDiff_scheduler.py:92-100,134)."""
+    var = sched.betas * (1.0 - sched.alphas_cumprod_prev) / (1.0 - sched.alphas_cumprod)
+    var = var.clip(1e-20)
+    sigma = var ** 0.5
+    sigma[0] = 0.0
+    return torch.stack([sched.sqrt_inv_alphas_cumprod, sched.sqrt_inv_alphas_cumprod_minus_one,
+                        sched.posterior_mean_coef1, sched.posterior_mean_coef2, sigma], dim=1).contiguous().float()
+
+
+class ReverseSampler:
+    """The sample_stDiff loop (model/sample.py:56-95) on one device for `R` rows in reference chunks.
+
+    Loop-invariant work is hoisted: cond_layer(x_cond) once (x_cond never changes, sample.py:9-16) and the time MLP
+    once per timestep into a [T,H] table (all rows of a step share t, sample.py:11).  One reverse step
+    (silu -> denoiser -> DDPM update + splice -> t -= 1) is captured into a hipGraph and replayed."""
+
+    def __init__(self, engine, sched, chunk_lens, x_cond, gt, mask, pred_type="noise", row_offset=0, seed=0,
+                 use_graph=True):
+        if pred_type not in ("noise", "x_start"):
+            raise NotImplementedError()                                  # stDiff_scheduler.py:125-126
+        pw = engine.pw
+        self.engine, self.pw = engine, pw
+        self.ws = engine.workspace(chunk_lens)
+        self.T = len(sched)
+        self.gt, self.mask = gt, mask
+        self.pred_type = 0 if pred_type == "noise" else 1
+        self.row_offset, self.seed, self.use_graph = int(row_offset), int(seed), use_graph
+        dev = pw.device
+        self.coef = step_coefficients(sched).to(dev)
+        self.temb = engine.time_embed(torch.arange(self.T, device=dev, dtype=torch.int64))     # [T,H]
+        self.ycond = engine.cond_embed(x_cond)                                                 # [R,H]
+        self.x = torch.empty((self.ws.R, pw.G), device=dev, dtype=torch.float32)
+        self.t_dev = torch.zeros((1,), device=dev, dtype=torch.int32)
+        self.graph = None
+        self._graph_z = None
+        self.stream = None
+
+    def init(self, x_T=None):
+        ops.init_sample(self.x, self.gt, self.mask, z=x_T, seed=self.seed, row_offset=self.row_offset, xp=self.ws.xp)
+
+    def _enqueue_step(self, t_first, z_base):
+        ws = self.ws
+        ops.silu_cond(self.ycond, temb=self.temb, t_index=self.t_dev, out=ws.s)
+        self.engine.run(ws)
+        ops.ddpm_step(self.x, ws.eps, self.gt, self.mask, self.coef, self.t_dev, t_first, z_base=z_base,
+                      seed=self.seed, row_offset=self.row_offset, xp=ws.xp, pred_type=self.pred_type)
+        ops.advance_timestep(self.t_dev)
+
+    def denoise_only(self, t):
+        """eps for the current x at timestep t (teacher-forced parity checks)."""
+        self.t_dev.fill_(int(t))
+        ops.silu_cond(self.ycond, temb=self.temb, t_index=self.t_dev, out=self.ws.s)
+        return self.engine.run(self.ws)
+
+    def set_x(self, x):
+        self.x.copy_(x)
+        ops.pack_rows(self.x, self.pw.Gp, self.pw.tdt, out=self.ws.xp)
+
+    def run(self, timesteps, z=None):
+        """timesteps: descending consecutive list (sample.py:57,63-64); z: optional injected noise [len-ish,R,G]
+        indexed by (timesteps[0] - t)."""
+        if not timesteps:
+            return self.x
+        t_first = int(timesteps[0])
+        assert list(timesteps) == list(range(t_first, t_first - len(timesteps), -1))
+        self.t_dev.fill_(t_first)
+        self._t_first, self._z, self._t_next = t_first, z, t_first
+        return self.run_more(len(timesteps))
+
+    def run_more(self, n):
+        """n further reverse steps from the device-side timestep counter."""
+        t_first, z = self._t_first, self._z
+        if n > self._t_next + 1:
+            raise ValueError(f"{n} more steps requested but only {self._t_next + 1} timesteps remain")
+        self._t_next -= n
+        timesteps = range(n)
+        if not self.use_graph:
+            for _ in timesteps:
+                self._enqueue_step(t_first, z)
+            return self.x
+        # the legacy default stream cannot be captured: capture and replay on a stream of our own
+        if self.stream is None:
+            self.stream = torch.cuda.Stream(device=self.pw.device)
+        cur = torch.cuda.current_stream()
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            if self.graph is None or self._graph_z != (ptr(z), t_first):
+                g = ops.Graph()
+                g.begin()
+                try:
+                    self._enqueue_step(t_first, z)
+                finally:
+                    g.end()
+                self.graph, self._graph_z = g, (ptr(z), t_first)
+            for _ in timesteps:
+                self.graph.launch()
+        cur.wait_stream(self.stream)
+        return self.x

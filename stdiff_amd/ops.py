@@ -1,0 +1,161 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point of include/stdiff_hip.h).
+Tensors must live on the GPU; outputs are allocated with torch when not supplied."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import BF16, F32, check, dt_of, lib, ptr, require_gpu, stream
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+def gemm(A, W, bias=None, out=None, out_dtype=None, epi=L.EPI_BIAS, gate=None, res=None, out2=None, M=None):
+    """out[M,N] = epi(A[M,K] @ W[N,K]^T + bias). A/W: same dtype (fp32 or bf16), K-contiguous rows."""
+    require_gpu(A, W, bias, out, gate, res, out2)
+    M = A.shape[0] if M is None else M
+    N, K = W.shape[0], W.shape[1]
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=out_dtype or A.dtype)
+    a = L.GemmArgs()
+    a.M, a.N, a.K = M, N, K
+    a.A, a.lda, a.a_dtype = ptr(A), A.stride(0), dt_of(A)
+    a.W, a.ldw = ptr(W), W.stride(0)
+    a.bias = ptr(bias)
+    a.C, a.ldc, a.c_dtype = ptr(out), out.stride(0), dt_of(out)
+    a.epi = epi
+    if gate is not None:
+        a.gate, a.ldgate = ptr(gate), gate.stride(0)
+    if res is not None:
+        a.res, a.ldres = ptr(res), res.stride(0)
+    if out2 is not None:
+        a.C2, a.ldc2 = ptr(out2), out2.stride(0)
+    check(lib().stdiff_gemm(C.byref(a), stream()))
+    return out
+
+
+def transpose(x, out=None):
+    require_gpu(x, out)
+    r, c = x.shape
+    if out is None:
+        out = torch.empty((c, r), device=x.device, dtype=x.dtype)
+    check(lib().stdiff_transpose(ptr(x), x.stride(0), ptr(out), out.stride(0), r, c, dt_of(x), stream()))
+    return out
+
+
+def attention_fwd(qkv, cu_rows, max_chunk, heads, out=None, lse=None):
+    """qkv [R,3H] -> out [R,H]; cu_rows int32 device [n_chunks+1]."""
+    require_gpu(qkv, cu_rows, out, lse)
+    R, H3 = qkv.shape
+    H = H3 // 3
+    if out is None:
+        out = torch.empty((R, H), device=qkv.device, dtype=qkv.dtype)
+    check(lib().stdiff_attention_fwd(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(lse), ptr(cu_rows),
+                                     cu_rows.numel() - 1, max_chunk, heads, H // heads, dt_of(qkv), stream()))
+    return out
+
+
+def ln_modulate(x, shift, scale, out=None, out_dtype=None, mean=None, rstd=None):
+    """LayerNorm(x, eps=1e-6, no affine) * (1 + scale) + shift; shift/scale are column views of the adaLN output."""
+    require_gpu(x, shift, scale, out)
+    R, H = x.shape
+    assert shift.stride(0) == scale.stride(0) and shift.dtype == scale.dtype
+    if out is None:
+        out = torch.empty((R, H), device=x.device, dtype=out_dtype or shift.dtype)
+    check(lib().stdiff_ln_modulate(ptr(x), x.stride(0), ptr(shift), ptr(scale), shift.stride(0), dt_of(shift),
+                                   ptr(out), out.stride(0), dt_of(out), ptr(mean), ptr(rstd), R, H, stream()))
+    return out
+
+
+def silu_cond(ycond, temb=None, t_index=None, out=None, out_dtype=torch.float32):
+    require_gpu(ycond, temb, t_index, out)
+    R, H = ycond.shape
+    if out is None:
+        out = torch.empty((R, H), device=ycond.device, dtype=out_dtype)
+    check(lib().stdiff_silu_cond(ptr(temb), ptr(t_index), ptr(ycond), ycond.stride(0), ptr(out), out.stride(0),
+                                 dt_of(out), R, H, stream()))
+    return out
+
+
+def timestep_embedding(t, freqs, out=None, out_dtype=torch.float32):
+    require_gpu(t, freqs, out)
+    assert t.dtype == torch.int64
+    R = t.numel()
+    if out is None:
+        out = torch.empty((R, 256), device=t.device, dtype=out_dtype)
+    check(lib().stdiff_timestep_embedding(ptr(t), ptr(freqs), ptr(out), out.stride(0), dt_of(out), R, stream()))
+    return out
+
+
+def pack_rows(src, cpad, dtype, out=None):
+    require_gpu(src, out)
+    R, Cc = src.shape
+    if out is None:
+        out = torch.empty((R, cpad), device=src.device, dtype=dtype)
+    check(lib().stdiff_pack_rows(ptr(src), src.stride(0), ptr(out), out.stride(0), dt_of(out), R, Cc, cpad, stream()))
+    return out
+
+
+def ddpm_step(x, eps, gt, mask, coef, t_dev, t_first, z_base=None, seed=0, row_offset=0, xp=None, pred_type=0):
+    require_gpu(x, eps, gt, mask, coef, t_dev, z_base, xp)
+    a = L.StepArgs()
+    a.x, a.eps, a.gt, a.mask, a.coef = ptr(x), ptr(eps), ptr(gt), ptr(mask), ptr(coef)
+    a.t_dev, a.t_first = ptr(t_dev), t_first
+    a.z_base, a.seed, a.row_offset = ptr(z_base), seed, row_offset
+    if xp is not None:
+        a.xp, a.ldxp, a.xp_dtype = ptr(xp), xp.stride(0), dt_of(xp)
+    a.R, a.G, a.pred_type = x.shape[0], x.shape[1], pred_type
+    check(lib().stdiff_ddpm_step(C.byref(a), stream()))
+
+
+def advance_timestep(t_dev):
+    check(lib().stdiff_advance_timestep(ptr(t_dev), stream()))
+
+
+def init_sample(x, gt, mask, z=None, seed=0, row_offset=0, xp=None):
+    require_gpu(x, gt, mask, z, xp)
+    check(lib().stdiff_init_sample(ptr(x), ptr(z), seed, row_offset, ptr(gt), ptr(mask), ptr(xp),
+                                   xp.stride(0) if xp is not None else 0, dt_of(xp) if xp is not None else F32,
+                                   x.shape[0], x.shape[1], stream()))
+
+
+def add_noise_splice(x, noise, t, sqrt_ac, sqrt_1mac, mask, x_noisy=None, xp=None):
+    require_gpu(x, noise, t, sqrt_ac, sqrt_1mac, mask, x_noisy, xp)
+    check(lib().stdiff_add_noise_splice(ptr(x), ptr(noise), ptr(t), ptr(sqrt_ac), ptr(sqrt_1mac), ptr(mask),
+                                        ptr(x_noisy), ptr(xp), xp.stride(0) if xp is not None else 0,
+                                        dt_of(xp) if xp is not None else F32, x.shape[0], x.shape[1], stream()))
+
+
+def masked_mse(pred, noise, mask, loss, dpred=None, dp=None, grad_scale=1.0):
+    require_gpu(pred, noise, mask, loss, dpred, dp)
+    check(lib().stdiff_masked_mse(ptr(pred), ptr(noise), ptr(mask), ptr(loss), ptr(dpred), ptr(dp),
+                                  dp.stride(0) if dp is not None else 0, dt_of(dp) if dp is not None else F32,
+                                  grad_scale, pred.shape[0], pred.shape[1], stream()))
+
+
+class Graph:
+    """hipGraph capture of everything enqueued on the current stream between begin() and end()."""
+
+    def __init__(self):
+        self.exec = None
+
+    def begin(self):
+        check(lib().stdiff_graph_begin(stream()))
+
+    def end(self):
+        h = C.c_void_p()
+        check(lib().stdiff_graph_end(stream(), C.byref(h)))
+        self.exec = h
+
+    def launch(self):
+        check(lib().stdiff_graph_launch(self.exec, stream()))
+
+    def __del__(self):
+        if self.exec is not None:
+            try:
+                lib().stdiff_graph_destroy(self.exec)
+            except Exception:
+                pass
+            self.exec = None

@@ -1,0 +1,35 @@
+"""Synthetic expression matrices and gene hold-out masks shaped like the reference driver's inputs
+(test-stDiff.py:47-55,73,92-108).  Host-side numpy only; used by bench.py, the tests and the golden generator."""
+import numpy as np
+
+
+def synth_expression(n, g, seed):
+    """Poisson-LogNormal counts -> normalize_total(1e4) -> log1p -> per-row max-abs scale: fp32 in [0, 1]."""
+    rng = np.random.default_rng(seed)
+    lam = rng.lognormal(0.0, 1.0, size=g)
+    s = rng.lognormal(0.0, 0.5, size=n)
+    out = np.empty((n, g), dtype=np.float32)
+    blk = 8192
+    for i in range(0, n, blk):
+        k = rng.poisson(lam[None, :] * s[i:i + blk, None]).astype(np.float64)
+        tot = k.sum(1, keepdims=True)
+        tot[tot == 0] = 1.0
+        k = np.log1p(k / tot * 1e4)
+        mx = np.abs(k).max(1, keepdims=True)
+        mx[mx == 0] = 1.0
+        out[i:i + blk] = (k / mx).astype(np.float32)
+    return out
+
+
+def kfold_mask(g, fold=0, n_splits=5, seed=0):
+    """mask of test-stDiff.py:73,92-96 without sklearn: KFold(shuffle=True, random_state) permutes arange(g) with
+    RandomState(seed) and cuts it into n_splits consecutive folds; test genes -> 0, known genes -> 1."""
+    idx = np.arange(g)
+    np.random.RandomState(seed).shuffle(idx)
+    sizes = np.full(n_splits, g // n_splits, dtype=int)
+    sizes[: g % n_splits] += 1
+    start = int(sizes[:fold].sum())
+    test = idx[start:start + sizes[fold]]
+    m = np.ones((g,), dtype=np.float32)
+    m[test] = 0
+    return m
