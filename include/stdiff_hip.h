@@ -43,7 +43,7 @@ enum {
     STDIFF_EPI_GELU = 2,      /* C = gelu_erf(v)                         (timm Mlp fc1+act, stDiff_model.py:100-103) */
     STDIFF_EPI_GATE_RES = 3,  /* C = res[m,n] + gate[m,n] * v  (fp32 C)  (gated residual, stDiff_model.py:114,116) */
     STDIFF_EPI_ADD = 4,       /* C = v + res[m,n]                        (c = t + y, stDiff_model.py:237) */
-    STDIFF_EPI_GELU_SAVE = 5, /* C = gelu_erf(v), C2 = v                 (training: keep the pre-activation) */
+    STDIFF_EPI_GELU_SAVE = 5, /* C = gelu_erf(v), C2 = v (C2 required)   (training: keep the pre-activation) */
     STDIFF_EPI_ACCUM = 6      /* C = C + v  (fp32 C)                      (gradient accumulation) */
 };
 
@@ -54,7 +54,8 @@ const char* stdiff_error_string(int status);
  * C[M,N] = epi(A[M,K] . W[N,K]^T + bias): the nn.Linear layers of stDiff_model.py
  * (:18,20 qkv/proj; :54,56 time MLP; :107,132 adaLN; :128 out; :177,180 in/cond; timm Mlp fc1/fc2).
  * A and W share a_dtype; K % 64 == 0 (bf16) or K % 16 == 0 (f32); lda/ldw multiples of 8 (bf16) / 4 (f32)
- * elements and A/W 16-byte aligned; M, N arbitrary. gate has a_dtype, res is fp32. */
+ * elements and A/W 16-byte aligned; M, N arbitrary. gate has a_dtype, res is fp32.  With ANY epilogue a non-NULL
+ * C2 (a_dtype, ldc2) additionally receives v itself -- the training forward keeps pre-activations / branch outputs. */
 typedef struct {
     int M, N, K;
     const void* A; int lda; int a_dtype;
@@ -68,8 +69,10 @@ typedef struct {
 } stdiff_gemm_args;
 int stdiff_gemm(const stdiff_gemm_args* a, void* stream);
 
-/* out[C,R] = in[R,C]^T (same dtype); used to turn the TN/NN backward contractions into NT GEMMs. */
-int stdiff_transpose(const void* in, int ld_in, void* out, int ld_out, int rows, int cols, int dtype, void* stream);
+/* out[c, r] = in[r, c] for r < rows, and 0 for rows <= r < rows_pad (same dtype, ld_out >= rows_pad): turns the
+ * TN / NN contractions of the backward pass (dW = dY^T X, dX = dY W) into NT GEMMs with a zero-padded K. */
+int stdiff_transpose(const void* in, int ld_in, void* out, int ld_out, int rows, int cols, int rows_pad, int dtype,
+                     void* stream);
 
 /* ---------------------------------------------------------------- cell-axis attention
  * Attention2.forward core (stDiff_model.py:25-34): per chunk (consecutive rows cu_rows[c]..cu_rows[c+1]) and
@@ -79,11 +82,12 @@ int stdiff_transpose(const void* in, int ld_in, void* out, int ld_out, int rows,
 int stdiff_attention_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, const int32_t* cu_rows,
                          int n_chunks, int max_chunk_rows, int heads, int head_dim, int dtype, void* stream);
 
-/* backward of the above: dqkv[R,3H] from dout[R,H], recomputing P from qkv and lse.
- * delta (fp32 [R, heads]) is scratch supplied by the caller. */
+/* backward of the above: dqkv[R,3H] (all three column blocks written) from dout[R,H], recomputing P from qkv and
+ * lse in two passes (dQ with the query on the lane; dK/dV with the key on the lane; no atomics).
+ * delta (fp32 [R, heads]) is scratch supplied by the caller; R = total_rows = cu_rows[n_chunks]. */
 int stdiff_attention_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const void* dout, int lddo,
                          const float* lse, float* delta, void* dqkv, int lddqkv, const int32_t* cu_rows, int n_chunks,
-                         int max_chunk_rows, int heads, int head_dim, int dtype, void* stream);
+                         int max_chunk_rows, int total_rows, int heads, int head_dim, int dtype, void* stream);
 
 /* ---------------------------------------------------------------- bandwidth-bound fused kernels
  * y = LayerNorm(x; eps 1e-6, no affine, biased var) * (1 + scale) + shift   (modulate, stDiff_model.py:41-44,96,99,126)
@@ -152,24 +156,28 @@ int stdiff_gate_bwd(const float* dh, int lddh, const void* gate, int ldgate, con
                     void* dbranch, int lddb, void* dgate, int lddg, int dtype, int R, int H, void* stream);
 /* du = dg * gelu'(u_pre)  (erf GELU) */
 int stdiff_gelu_bwd(const void* dg, const void* u_pre, void* du, int ld, int dtype, int R, int C, void* stream);
-/* dc += ds * silu'(c);  ds in dtype, c/dc fp32 */
-int stdiff_silu_bwd(const void* ds, int ldds, int dtype, const float* c, float* dc, int ldc, int accumulate, int R,
-                    int H, void* stream);
+/* dc (+)= ds * silu'(c)   (nn.SiLU backward: conditioning vector stDiff_model.py:106,131 and time MLP :55);
+ * each of ds / c / dc may be fp32 or bf16. */
+int stdiff_silu_bwd(const void* ds, int ldds, int ds_dtype, const void* c, int ldc, int c_dtype, void* dc, int lddc,
+                    int dc_dtype, int accumulate, int R, int H, void* stream);
 /* db[n] (+)= sum_m dY[m,n]   (bias gradients) */
 int stdiff_colsum(const void* dY, int ld, int dtype, float* db, int accumulate, int R, int C, void* stream);
 
 /* ---------------------------------------------------------------- optimizer (stDiff_train.py:47,78-80)
- * Multi-tensor: tensors are described by device arrays of pointers / sizes built once by the caller. */
-/* sumsq[0] += sum over all tensors of g^2 (caller zeroes it). */
-int stdiff_grad_sumsq(const float* const* grads, const int64_t* sizes, int n_tensors, float* sumsq, void* stream);
-/* clip_grad_norm_(1.0) + AdamW(weight_decay) in one pass: coef = min(1, max_norm/(sqrt(*sumsq)*inv_world+1e-6));
- * g *= inv_world*coef; m,v,p update with bias correction for `step` (1-based). Also refreshes the bf16 operand
- * copies p16[i] when non-null. */
+ * All trainable parameters live in ONE flat fp32 buffer (so do grads and the two Adam moments); under data
+ * parallelism the flat gradient buffer is what RCCL all-reduces. */
+/* *sumsq += sum g^2 (caller zeroes it). */
+int stdiff_grad_sumsq(const float* grads, int64_t n, float* sumsq, void* stream);
+/* nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.AdamW step in one pass (28 B/param):
+ *   step = ++*step_dev;  norm = sqrt(*sumsq) * grad_scale;  coef = min(1, max_norm / (norm + 1e-6)) * grad_scale
+ *   g' = g*coef;  p *= 1 - lr*wd;  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;
+ *   p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)
+ * grad_scale = 1/world_size when `grads` holds an all-reduced SUM.  The step counter and the derived scalars live on
+ * the device (step_dev int32[1]; scal fp32[4] = {coef, lr/bc1, sqrt(bc2), norm}) so a captured train step replays. */
 typedef struct {
-    float* const* params; const float* const* grads; float* const* exp_avg; float* const* exp_avg_sq;
-    void* const* p16; const int64_t* sizes; int n_tensors;
-    const float* sumsq; float max_norm; float inv_world;
-    float lr, beta1, beta2, eps, weight_decay; int step;
+    float* params; const float* grads; float* exp_avg; float* exp_avg_sq; int64_t n;
+    const float* sumsq; int32_t* step_dev; float* scal;
+    float max_norm, grad_scale, lr, beta1, beta2, eps, weight_decay;
 } stdiff_adamw_args;
 int stdiff_clip_adamw(const stdiff_adamw_args* a, void* stream);
 

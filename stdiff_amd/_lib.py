@@ -51,16 +51,17 @@ class DitWorkspace(C.Structure):
 
 
 class AdamWArgs(C.Structure):
-    _fields_ = [("params", vp), ("grads", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("p16", vp), ("sizes", vp),
-                ("n_tensors", i32), ("sumsq", vp), ("max_norm", f32), ("inv_world", f32),
-                ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("weight_decay", f32), ("step", i32)]
+    _fields_ = [("params", vp), ("grads", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("n", i64),
+                ("sumsq", vp), ("step_dev", vp), ("scal", vp),
+                ("max_norm", f32), ("grad_scale", f32), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32),
+                ("weight_decay", f32)]
 
 
 _SIGS = {
     "stdiff_abi_version": (i32, []),
     "stdiff_error_string": (C.c_char_p, [i32]),
     "stdiff_gemm": (i32, [C.POINTER(GemmArgs), vp]),
-    "stdiff_transpose": (i32, [vp, i32, vp, i32, i32, i32, i32, vp]),
+    "stdiff_transpose": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "stdiff_attention_fwd": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "stdiff_ln_modulate": (i32, [vp, i32, vp, vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, vp]),
     "stdiff_silu_cond": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]),
@@ -71,6 +72,14 @@ _SIGS = {
     "stdiff_init_sample": (i32, [vp, vp, u64, i64, vp, vp, vp, i32, i32, i32, i32, vp]),
     "stdiff_add_noise_splice": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "stdiff_masked_mse": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp]),
+    "stdiff_attention_bwd": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "stdiff_ln_modulate_bwd": (i32, [vp, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, vp, vp, i32, i32, i32, vp]),
+    "stdiff_gate_bwd": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
+    "stdiff_gelu_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "stdiff_silu_bwd": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp]),
+    "stdiff_colsum": (i32, [vp, i32, i32, vp, i32, i32, i32, vp]),
+    "stdiff_grad_sumsq": (i32, [vp, i64, vp, vp]),
+    "stdiff_clip_adamw": (i32, [C.POINTER(AdamWArgs), vp]),
     "stdiff_dit_forward": (i32, [C.POINTER(DitWeights), C.POINTER(DitWorkspace), vp, vp, vp, i32, vp]),
     "stdiff_graph_begin": (i32, [vp]),
     "stdiff_graph_end": (i32, [vp, C.POINTER(vp)]),

@@ -121,8 +121,8 @@ __device__ __forceinline__ void epilogue8(const Params& p, int gm, int gn, const
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = pre[j];
     }
-    auto store = [&](void* base, int ld, const float* w) {
-        if (p.c_bf16) {
+    auto store = [&](void* base, int ld, const float* w, bool bf) {
+        if (bf) {
             bf16_t* c = (bf16_t*)base + (size_t)gm * ld + gn;
             if (p.vec) {
                 u32x4 pk;
@@ -142,8 +142,8 @@ __device__ __forceinline__ void epilogue8(const Params& p, int gm, int gn, const
             }
         }
     };
-    store(p.C, p.ldc, o);
-    if (p.epi == STDIFF_EPI_GELU_SAVE) store(p.C2, p.ldc2, pre);
+    store(p.C, p.ldc, o, p.c_bf16);
+    if (p.C2) store(p.C2, p.ldc2, pre, sizeof(T) == 2);   // pre-activation v, kept in the operand dtype
 }
 
 template <typename T>
@@ -273,18 +273,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
 
 // ---------------------------------------------------------------- transpose (bf16 / f32), 64x64 tiles through LDS
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_kernel(const T* in, int ldi, T* out, int ldo, int rows, int cols) {
+__global__ __launch_bounds__(256) void transpose_kernel(const T* in, int ldi, T* out, int ldo, int rows, int cols,
+                                                        int rows_pad) {
     __shared__ T tile[64][65];
     int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4) {
         int r = r0 + i, c = c0 + tx;
-        if (r < rows && c < cols) tile[i][tx] = in[(size_t)r * ldi + c];
+        tile[i][tx] = (r < rows && c < cols) ? in[(size_t)r * ldi + c] : (T)0;
     }
     __syncthreads();
     for (int i = ty; i < 64; i += 4) {
         int c = c0 + i, r = r0 + tx;
-        if (r < rows && c < cols) out[(size_t)c * ldo + r] = tile[tx][i];
+        if (r < rows_pad && c < cols) out[(size_t)c * ldo + r] = tile[tx][i];   // rows..rows_pad-1: zeros
     }
 }
 
@@ -320,7 +321,7 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
     if (a->epi == STDIFF_EPI_GATE_RES)
         vec = vec && al16(a->gate) && a->ldgate % epv == 0 && al16(a->res) && a->ldres % 4 == 0;
     if (a->epi == STDIFF_EPI_ADD) vec = vec && al16(a->res) && a->ldres % 4 == 0;
-    if (a->epi == STDIFF_EPI_GELU_SAVE) vec = vec && al16(a->C2) && a->ldc2 % cel == 0;
+    if (a->C2) vec = vec && al16(a->C2) && a->ldc2 % epv == 0 && a->ldc2 >= a->N;
     p.vec = vec;
     p.tiles_m = cdiv(a->M, BM);
     p.tiles_n = cdiv(a->N, BN);
@@ -333,18 +334,18 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
     return STDIFF_OK;
 }
 
-extern "C" int stdiff_transpose(const void* in, int ld_in, void* out, int ld_out, int rows, int cols, int dtype,
-                                void* stream) {
-    STDIFF_CHECK_ARG(in && out && rows >= 0 && cols >= 0 && ld_in >= cols && ld_out >= rows);
+extern "C" int stdiff_transpose(const void* in, int ld_in, void* out, int ld_out, int rows, int cols, int rows_pad,
+                                int dtype, void* stream) {
+    STDIFF_CHECK_ARG(in && out && rows >= 0 && cols >= 0 && ld_in >= cols && rows_pad >= rows && ld_out >= rows_pad);
     STDIFF_CHECK_ARG(dtype == STDIFF_F32 || dtype == STDIFF_BF16);
     if (rows == 0 || cols == 0) return STDIFF_OK;
-    dim3 grid(cdiv(cols, 64), cdiv(rows, 64)), block(256);
+    dim3 grid(cdiv(cols, 64), cdiv(rows_pad, 64)), block(256);
     if (dtype == STDIFF_BF16)
         hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)in, ld_in,
-                           (bf16_t*)out, ld_out, rows, cols);
+                           (bf16_t*)out, ld_out, rows, cols, rows_pad);
     else
         hipLaunchKernelGGL(transpose_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)in, ld_in,
-                           (float*)out, ld_out, rows, cols);
+                           (float*)out, ld_out, rows, cols, rows_pad);
     STDIFF_LAUNCH_STATUS();
     return STDIFF_OK;
 }

@@ -1,0 +1,341 @@
+// Backward-pass and optimizer kernels of normal_train_stDiff (stDiff_train.py:56-81); all HBM-bound.
+//   ln_modulate_bwd : d(LayerNorm*(1+scale)+shift)   -> dx (fp32), dshift, dscale
+//   gate_bwd        : d(x + gate*branch)             -> dbranch, dgate
+//   gelu_bwd        : erf-GELU derivative
+//   silu_bwd        : SiLU derivative (conditioning vector and time MLP)
+//   colsum          : bias gradients
+//   grad_sumsq / clip_adamw : clip_grad_norm_(1.0) + AdamW(weight_decay) over ONE flat fp32 parameter buffer
+#include "common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ float ldf(const void* p, size_t i) { return Elem<T>::ld((const T*)p + i); }
+
+// ---------------------------------------------------------------- LayerNorm-modulate backward, one wave per row
+// y = xhat*(1+scale)+shift, xhat = (x-mean)*rstd:  g = dy*(1+scale);  dx = rstd*(g - mean(g) - xhat*mean(g*xhat))
+template <int NV, typename T>
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const T* dy, int lddy, const float* x, int ldx,
+                                                         const float* mean, const float* rstd, const T* scale,
+                                                         int ldmod, float* dx, int lddx, int accumulate, T* dshift,
+                                                         T* dscale, int lddmod, int R, int H) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 g[NV], xh[NV];
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int c = (i * 64 + lane) * 4;
+        if (c < H) {
+            f32x4 d = ld4(dy + (size_t)row * lddy + c), xv = *(const f32x4*)(x + (size_t)row * ldx + c),
+                  sc = ld4(scale + (size_t)row * ldmod + c), ds;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xh[i][j] = (xv[j] - mu) * rs;
+                g[i][j] = d[j] * (1.0f + sc[j]);
+                ds[j] = d[j] * xh[i][j];
+                sg += g[i][j];
+                sgx += g[i][j] * xh[i][j];
+            }
+            st4(dshift + (size_t)row * lddmod + c, d);
+            st4(dscale + (size_t)row * lddmod + c, ds);
+        } else {
+            g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            xh[i] = g[i];
+        }
+    }
+    const float mg = wave_sum(sg) / (float)H, mgx = wave_sum(sgx) / (float)H;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int c = (i * 64 + lane) * 4;
+        if (c < H) {
+            float* dp = dx + (size_t)row * lddx + c;
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = rs * (g[i][j] - mg - xh[i][j] * mgx);
+            if (accumulate) {
+                f32x4 old = *(const f32x4*)dp;
+                o += old;
+            }
+            *(f32x4*)dp = o;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* dh, int lddh, const T* gate, int ldgate,
+                                                       const T* branch, int ldbr, T* dbranch, int lddb, T* dgate,
+                                                       int lddg, int R, int H) {
+    const int hv = H >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)R * hv;
+         i += (size_t)gridDim.x * blockDim.x) {
+        int r = (int)(i / hv), c = (int)(i % hv) * 4;
+        f32x4 d = *(const f32x4*)(dh + (size_t)r * lddh + c), g = ld4(gate + (size_t)r * ldgate + c),
+              b = ld4(branch + (size_t)r * ldbr + c);
+        st4(dbranch + (size_t)r * lddb + c, d * g);
+        st4(dgate + (size_t)r * lddg + c, d * b);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* dg, const T* u, T* du, int ld, int R, int C) {
+    const int cv = C >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)R * cv;
+         i += (size_t)gridDim.x * blockDim.x) {
+        int r = (int)(i / cv), c = (int)(i % cv) * 4;
+        f32x4 d = ld4(dg + (size_t)r * ld + c), v = ld4(u + (size_t)r * ld + c), o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = v[j];
+            float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+            float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+            o[j] = d[j] * (cdf + x * pdf);
+        }
+        st4(du + (size_t)r * ld + c, o);
+    }
+}
+
+template <typename TD, typename TC, typename TO>
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const TD* ds, int ldds, const TC* c, int ldc, TO* dc, int lddc,
+                                                       int accumulate, int R, int H) {
+    const int hv = H >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)R * hv;
+         i += (size_t)gridDim.x * blockDim.x) {
+        int r = (int)(i / hv), col = (int)(i % hv) * 4;
+        f32x4 d = ld4(ds + (size_t)r * ldds + col), v = ld4(c + (size_t)r * ldc + col), o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float sg = 1.0f / (1.0f + expf(-v[j]));
+            o[j] = d[j] * sg * (1.0f + v[j] * (1.0f - sg));
+        }
+        TO* out = dc + (size_t)r * lddc + col;
+        if (accumulate) {
+            f32x4 old = ld4(out);
+            o += old;
+        }
+        st4(out, o);
+    }
+}
+
+// db[c] (+)= sum_r dY[r,c]: block = 64 columns x 4 row groups
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* dY, int ld, float* db, int accumulate, int R, int C) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C)
+        for (int r = g; r < R; r += 4) s += Elem<T>::ld(dY + (size_t)r * ld + c);
+    part[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        db[c] = accumulate ? db[c] + t : t;
+    }
+}
+
+// ---------------------------------------------------------------- optimizer over a flat buffer
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, int64_t n, float* out) {
+    float acc = 0.f;
+    const int64_t nv = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 v = *(const f32x4*)(g + 4 * i);
+        acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = nv * 4; i < n; ++i) acc += g[i] * g[i];
+    acc = wave_sum(acc);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+// torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW, one pass: 16 B read of p,g,m,v, 12 B write -> 28 B/param
+__global__ void adam_prep_kernel(const float* sumsq, int32_t* step_dev, float* scal, float max_norm, float gscale,
+                                 float lr, float b1, float b2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int step = *step_dev + 1;
+    *step_dev = step;
+    const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+    const float norm = sqrtf(*sumsq) * gscale;
+    scal[0] = fminf(max_norm / (norm + 1e-6f), 1.0f) * gscale;
+    scal[1] = (float)((double)lr / bc1);
+    scal[2] = (float)sqrt(bc2);
+    scal[3] = norm;
+}
+
+__global__ __launch_bounds__(256) void clip_adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n,
+                                                         const float* scal, float lr, float b1, float b2, float eps,
+                                                         float wd) {
+    const float coef = scal[0], step = scal[1], bc2_sqrt = scal[2];
+    const int64_t nv = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 pp = *(const f32x4*)(p + 4 * i), gg = *(const f32x4*)(g + 4 * i), mm = *(const f32x4*)(m + 4 * i),
+              vv = *(const f32x4*)(v + 4 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gr = gg[j] * coef;
+            pp[j] *= 1.0f - lr * wd;
+            mm[j] = mm[j] * b1 + gr * (1.0f - b1);
+            vv[j] = vv[j] * b2 + gr * gr * (1.0f - b2);
+            pp[j] -= step * (mm[j] / (sqrtf(vv[j]) / bc2_sqrt + eps));
+        }
+        *(f32x4*)(p + 4 * i) = pp;
+        *(f32x4*)(m + 4 * i) = mm;
+        *(f32x4*)(v + 4 * i) = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int64_t i = nv * 4; i < n; ++i) {
+            float gr = g[i] * coef;
+            p[i] *= 1.0f - lr * wd;
+            m[i] = m[i] * b1 + gr * (1.0f - b1);
+            v[i] = v[i] * b2 + gr * gr * (1.0f - b2);
+            p[i] -= step * (m[i] / (sqrtf(v[i]) / bc2_sqrt + eps));
+        }
+}
+
+inline int ew_grid(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 8); }
+inline bool al16(const void* p) { return p == nullptr || ((uintptr_t)p & 15) == 0; }
+inline bool al8(const void* p) { return p == nullptr || ((uintptr_t)p & 7) == 0; }
+
+template <typename T>
+int launch_ln_bwd(const void* dy, int lddy, const float* x, int ldx, const float* mean, const float* rstd,
+                  const void* scale, int ldmod, float* dx, int lddx, int acc, void* dshift, void* dscale, int lddmod,
+                  int R, int H, hipStream_t st) {
+    dim3 grid(cdiv(R, 4)), block(256);
+#define CASE(NV)                                                                                                   \
+    hipLaunchKernelGGL((ln_mod_bwd_kernel<NV, T>), grid, block, 0, st, (const T*)dy, lddy, x, ldx, mean, rstd,     \
+                       (const T*)scale, ldmod, dx, lddx, acc, (T*)dshift, (T*)dscale, lddmod, R, H)
+    if (H <= 256) CASE(1);
+    else if (H <= 512) CASE(2);
+    else if (H <= 1024) CASE(4);
+    else if (H <= 2048) CASE(8);
+    else if (H <= 4096) CASE(16);
+    else return STDIFF_ERR_SHAPE;
+#undef CASE
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}
+
+}  // namespace
+
+extern "C" int stdiff_ln_modulate_bwd(const void* dy, int lddy, int dtype, const float* x, int ldx, const float* mean,
+                                      const float* rstd, const void* scale, int ldmod, float* dx, int lddx,
+                                      int accumulate, void* dshift, void* dscale, int lddmod, int R, int H,
+                                      void* stream) {
+    STDIFF_CHECK_ARG(dy && x && mean && rstd && scale && dx && dshift && dscale && R >= 0 && H > 0);
+    STDIFF_CHECK_ARG(dtype == STDIFF_F32 || dtype == STDIFF_BF16);
+    if (R == 0) return STDIFF_OK;
+    if (H % 4) return STDIFF_ERR_SHAPE;
+    if (lddy % 4 || ldx % 4 || ldmod % 4 || lddx % 4 || lddmod % 4 || !al16(x) || !al16(dx) || !al8(dy) || !al8(scale) ||
+        !al8(dshift) || !al8(dscale))
+        return STDIFF_ERR_ALIGN;
+    if (dtype == STDIFF_BF16)
+        return launch_ln_bwd<bf16_t>(dy, lddy, x, ldx, mean, rstd, scale, ldmod, dx, lddx, accumulate, dshift, dscale,
+                                     lddmod, R, H, (hipStream_t)stream);
+    return launch_ln_bwd<float>(dy, lddy, x, ldx, mean, rstd, scale, ldmod, dx, lddx, accumulate, dshift, dscale,
+                                lddmod, R, H, (hipStream_t)stream);
+}
+
+extern "C" int stdiff_gate_bwd(const float* dh, int lddh, const void* gate, int ldgate, const void* branch, int ldbr,
+                               void* dbranch, int lddb, void* dgate, int lddg, int dtype, int R, int H, void* stream) {
+    STDIFF_CHECK_ARG(dh && gate && branch && dbranch && dgate && R >= 0 && H > 0);
+    STDIFF_CHECK_ARG(dtype == STDIFF_F32 || dtype == STDIFF_BF16);
+    if (R == 0) return STDIFF_OK;
+    if (H % 4) return STDIFF_ERR_SHAPE;
+    if (lddh % 4 || ldgate % 4 || ldbr % 4 || lddb % 4 || lddg % 4 || !al16(dh) || !al8(gate) || !al8(branch) ||
+        !al8(dbranch) || !al8(dgate))
+        return STDIFF_ERR_ALIGN;
+    dim3 grid(ew_grid((size_t)R * H / 4)), block(256);
+    if (dtype == STDIFF_BF16)
+        hipLaunchKernelGGL(gate_bwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, dh, lddh, (const bf16_t*)gate,
+                           ldgate, (const bf16_t*)branch, ldbr, (bf16_t*)dbranch, lddb, (bf16_t*)dgate, lddg, R, H);
+    else
+        hipLaunchKernelGGL(gate_bwd_kernel<float>, grid, block, 0, (hipStream_t)stream, dh, lddh, (const float*)gate,
+                           ldgate, (const float*)branch, ldbr, (float*)dbranch, lddb, (float*)dgate, lddg, R, H);
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}
+
+extern "C" int stdiff_gelu_bwd(const void* dg, const void* u_pre, void* du, int ld, int dtype, int R, int C,
+                               void* stream) {
+    STDIFF_CHECK_ARG(dg && u_pre && du && R >= 0 && C > 0 && ld >= C);
+    STDIFF_CHECK_ARG(dtype == STDIFF_F32 || dtype == STDIFF_BF16);
+    if (R == 0) return STDIFF_OK;
+    if (C % 4) return STDIFF_ERR_SHAPE;
+    if (ld % 4 || !al8(dg) || !al8(u_pre) || !al8(du)) return STDIFF_ERR_ALIGN;
+    dim3 grid(ew_grid((size_t)R * C / 4)), block(256);
+    if (dtype == STDIFF_BF16)
+        hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dg,
+                           (const bf16_t*)u_pre, (bf16_t*)du, ld, R, C);
+    else
+        hipLaunchKernelGGL(gelu_bwd_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)dg,
+                           (const float*)u_pre, (float*)du, ld, R, C);
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}
+
+extern "C" int stdiff_silu_bwd(const void* ds, int ldds, int ds_dtype, const void* c, int ldc, int c_dtype, void* dc,
+                               int lddc, int dc_dtype, int accumulate, int R, int H, void* stream) {
+    STDIFF_CHECK_ARG(ds && c && dc && R >= 0 && H > 0);
+    if (R == 0) return STDIFF_OK;
+    if (H % 4) return STDIFF_ERR_SHAPE;
+    if (ldds % 4 || ldc % 4 || lddc % 4 || !al8(ds) || !al8(c) || !al8(dc)) return STDIFF_ERR_ALIGN;
+    if (ds_dtype == STDIFF_F32 && (!al16(ds))) return STDIFF_ERR_ALIGN;
+    dim3 grid(ew_grid((size_t)R * H / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const int key = (ds_dtype == STDIFF_BF16) * 4 + (c_dtype == STDIFF_BF16) * 2 + (dc_dtype == STDIFF_BF16);
+#define SB(TD, TC, TO)                                                                                       \
+    hipLaunchKernelGGL((silu_bwd_kernel<TD, TC, TO>), grid, block, 0, st, (const TD*)ds, ldds, (const TC*)c, \
+                       ldc, (TO*)dc, lddc, accumulate, R, H)
+    switch (key) {
+        case 0: SB(float, float, float); break;
+        case 1: SB(float, float, bf16_t); break;
+        case 2: SB(float, bf16_t, float); break;
+        case 3: SB(float, bf16_t, bf16_t); break;
+        case 4: SB(bf16_t, float, float); break;
+        case 5: SB(bf16_t, float, bf16_t); break;
+        case 6: SB(bf16_t, bf16_t, float); break;
+        default: SB(bf16_t, bf16_t, bf16_t); break;
+    }
+#undef SB
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}
+
+extern "C" int stdiff_colsum(const void* dY, int ld, int dtype, float* db, int accumulate, int R, int C, void* stream) {
+    STDIFF_CHECK_ARG(dY && db && R >= 0 && C > 0 && ld >= C);
+    STDIFF_CHECK_ARG(dtype == STDIFF_F32 || dtype == STDIFF_BF16);
+    dim3 grid(cdiv(C, 64)), block(256);
+    if (dtype == STDIFF_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, (const bf16_t*)dY, ld, db,
+                           accumulate, R, C);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, (hipStream_t)stream, (const float*)dY, ld, db,
+                           accumulate, R, C);
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}
+
+extern "C" int stdiff_grad_sumsq(const float* grads, int64_t n, float* sumsq, void* stream) {
+    STDIFF_CHECK_ARG(grads && sumsq && n >= 0 && al16(grads));
+    if (n == 0) return STDIFF_OK;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(ew_grid((size_t)n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, grads, n, sumsq);
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}
+
+extern "C" int stdiff_clip_adamw(const stdiff_adamw_args* a, void* stream) {
+    STDIFF_CHECK_ARG(a && a->params && a->grads && a->exp_avg && a->exp_avg_sq && a->sumsq && a->step_dev && a->scal &&
+                     a->n >= 0);
+    STDIFF_CHECK_ARG(al16(a->params) && al16(a->grads) && al16(a->exp_avg) && al16(a->exp_avg_sq));
+    if (a->n == 0) return STDIFF_OK;
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->sumsq, a->step_dev, a->scal,
+                       a->max_norm, a->grad_scale, a->lr, a->beta1, a->beta2);
+    hipLaunchKernelGGL(clip_adamw_kernel, dim3(ew_grid((size_t)a->n / 4 + 1)), dim3(256), 0, (hipStream_t)stream,
+                       a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->n, a->scal, a->lr, a->beta1, a->beta2,
+                       a->eps, a->weight_decay);
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}

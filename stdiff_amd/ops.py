@@ -36,12 +36,14 @@ def gemm(A, W, bias=None, out=None, out_dtype=None, epi=L.EPI_BIAS, gate=None, r
     return out
 
 
-def transpose(x, out=None):
+def transpose(x, out=None, rows_pad=None):
+    """out[c, r] = x[r, c]; columns rows..rows_pad-1 of out are zero-filled (K padding of the backward GEMMs)."""
     require_gpu(x, out)
     r, c = x.shape
+    rows_pad = r if rows_pad is None else rows_pad
     if out is None:
-        out = torch.empty((c, r), device=x.device, dtype=x.dtype)
-    check(lib().stdiff_transpose(ptr(x), x.stride(0), ptr(out), out.stride(0), r, c, dt_of(x), stream()))
+        out = torch.empty((c, rows_pad), device=x.device, dtype=x.dtype)
+    check(lib().stdiff_transpose(ptr(x), x.stride(0), ptr(out), out.stride(0), r, c, rows_pad, dt_of(x), stream()))
     return out
 
 
@@ -133,6 +135,73 @@ def masked_mse(pred, noise, mask, loss, dpred=None, dp=None, grad_scale=1.0):
     check(lib().stdiff_masked_mse(ptr(pred), ptr(noise), ptr(mask), ptr(loss), ptr(dpred), ptr(dp),
                                   dp.stride(0) if dp is not None else 0, dt_of(dp) if dp is not None else F32,
                                   grad_scale, pred.shape[0], pred.shape[1], stream()))
+
+
+def attention_bwd(qkv, out, dout, lse, cu_rows, max_chunk, heads, dqkv=None, delta=None):
+    require_gpu(qkv, out, dout, lse, cu_rows, dqkv, delta)
+    R, H3 = qkv.shape
+    H = H3 // 3
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    if delta is None:
+        delta = torch.empty((R, heads), device=qkv.device, dtype=torch.float32)
+    check(lib().stdiff_attention_bwd(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(dout), dout.stride(0),
+                                     ptr(lse), ptr(delta), ptr(dqkv), dqkv.stride(0), ptr(cu_rows),
+                                     cu_rows.numel() - 1, max_chunk, R, heads, H // heads, dt_of(qkv), stream()))
+    return dqkv
+
+
+def ln_modulate_bwd(dy, x, mean, rstd, scale, dx, dshift, dscale, accumulate=True):
+    require_gpu(dy, x, mean, rstd, scale, dx, dshift, dscale)
+    R, H = x.shape
+    assert dshift.stride(0) == dscale.stride(0)
+    check(lib().stdiff_ln_modulate_bwd(ptr(dy), dy.stride(0), dt_of(dy), ptr(x), x.stride(0), ptr(mean), ptr(rstd),
+                                       ptr(scale), scale.stride(0), ptr(dx), dx.stride(0), int(accumulate),
+                                       ptr(dshift), ptr(dscale), dshift.stride(0), R, H, stream()))
+
+
+def gate_bwd(dh, gate, branch, dbranch, dgate):
+    require_gpu(dh, gate, branch, dbranch, dgate)
+    R, H = dh.shape
+    check(lib().stdiff_gate_bwd(ptr(dh), dh.stride(0), ptr(gate), gate.stride(0), ptr(branch), branch.stride(0),
+                                ptr(dbranch), dbranch.stride(0), ptr(dgate), dgate.stride(0), dt_of(gate), R, H,
+                                stream()))
+
+
+def gelu_bwd(dg, u_pre, du):
+    require_gpu(dg, u_pre, du)
+    R, Cc = dg.shape
+    assert dg.stride(0) == u_pre.stride(0) == du.stride(0)
+    check(lib().stdiff_gelu_bwd(ptr(dg), ptr(u_pre), ptr(du), dg.stride(0), dt_of(dg), R, Cc, stream()))
+
+
+def silu_bwd(ds, c, dc, accumulate=False):
+    require_gpu(ds, c, dc)
+    R, H = ds.shape
+    check(lib().stdiff_silu_bwd(ptr(ds), ds.stride(0), dt_of(ds), ptr(c), c.stride(0), dt_of(c), ptr(dc),
+                                dc.stride(0), dt_of(dc), int(accumulate), R, H, stream()))
+
+
+def colsum(dY, db, accumulate=False):
+    require_gpu(dY, db)
+    R, Cc = dY.shape
+    check(lib().stdiff_colsum(ptr(dY), dY.stride(0), dt_of(dY), ptr(db), int(accumulate), R, Cc, stream()))
+
+
+def grad_sumsq(g, sumsq):
+    require_gpu(g, sumsq)
+    check(lib().stdiff_grad_sumsq(ptr(g), g.numel(), ptr(sumsq), stream()))
+
+
+def clip_adamw(p, g, m, v, sumsq, step_dev, scal, lr, max_norm=1.0, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8,
+               weight_decay=0.0):
+    require_gpu(p, g, m, v, sumsq, step_dev, scal)
+    a = L.AdamWArgs()
+    a.params, a.grads, a.exp_avg, a.exp_avg_sq, a.n = ptr(p), ptr(g), ptr(m), ptr(v), p.numel()
+    a.sumsq, a.step_dev, a.scal = ptr(sumsq), ptr(step_dev), ptr(scal)
+    a.max_norm, a.grad_scale, a.lr = max_norm, grad_scale, lr
+    a.beta1, a.beta2, a.eps, a.weight_decay = betas[0], betas[1], eps, weight_decay
+    check(lib().stdiff_clip_adamw(C.byref(a), stream()))
 
 
 class Graph:

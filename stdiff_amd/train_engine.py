@@ -1,0 +1,323 @@
+"""Training side of the hot path: DiT_stDiff forward with saved activations, the hand-written backward, the masked
+diffusion loss and the fused clip+AdamW step of normal_train_stDiff (stDiff_train.py:56-81), all through
+libstdiff_hip.so.  Under data parallelism the flat gradient buffer is all-reduced with RCCL (torch.distributed
+backend "nccl"), one bucket per DiT block, overlapped with the rest of the backward pass."""
+import torch
+
+from . import _lib as L
+from . import engine as E
+from . import ops
+
+_NO_GRAD = ("condi_emb.weight",)      # unused by forward (stDiff_model.py:184,236): no gradient, skipped by clip/AdamW
+
+
+def flat_layout(named_sizes):
+    """Offsets of each tensor in the flat fp32 buffer (every tensor starts on a 16-byte boundary) and its length."""
+    offs, total = {}, 0
+    for n, numel in named_sizes:
+        offs[n] = total
+        total += (numel + 3) // 4 * 4
+    return offs, total
+
+
+def bucket_ranges(offs, total, depth):
+    """Contiguous [lo, hi) ranges of the flat gradient in the order backward completes them: final layer,
+    block depth-1 .. block 0, embedding layers.  These are the RCCL all-reduce buckets of data-parallel training."""
+    out0 = offs["out_layer.linear.weight"]
+    r = [(out0, total)]
+    for k in range(depth - 1, -1, -1):
+        lo = offs[f"blks.{k}.attn.qkv.weight"]
+        hi = offs[f"blks.{k + 1}.attn.qkv.weight"] if k + 1 < depth else out0
+        r.append((lo, hi))
+    r.append((0, offs["blks.0.attn.qkv.weight"]))
+    return r
+
+
+class TrainCore:
+    """Forward with saved activations + backward into ONE flat fp32 gradient buffer."""
+
+    def __init__(self, model):
+        self.model = model
+        params = dict(model.named_parameters())
+        dev = params["in_layer.0.weight"].device
+        if dev.type != "cuda":
+            raise RuntimeError("stdiff_amd runs on MI355X only: move the model with .to('cuda') (no CPU fallback)")
+        self.device = dev
+        self.names = [n for n in params if n not in _NO_GRAD]
+        # ---- flat parameter / gradient / moment buffers (each tensor starts on a 16-byte boundary)
+        offs, total = flat_layout([(n, params[n].numel()) for n in self.names])
+        self.offs, self.total = offs, total
+        flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for n in self.names:
+                p = params[n]
+                v = flat[offs[n]:offs[n] + p.numel()].view_as(p)
+                v.copy_(p.detach())
+                p.data = v
+        self.flat_p = flat
+        self.flat_g = torch.zeros_like(flat)
+        self.g = {n: self.flat_g[offs[n]:offs[n] + params[n].numel()].view_as(params[n]) for n in self.names}
+        self.eng = model.engine()          # packs the (now flat-backed) parameters
+        self.pw = self.eng.pw
+        pw = self.pw
+        self.G, self.Gp, self.H, self.depth, self.heads = pw.G, pw.Gp, pw.H, pw.depth, pw.heads
+        self.tdt = pw.tdt
+        # ---- transposed operand copies W^T [in, out] for the dX = dY.W contractions
+        self.wT = {}
+        for n, w in pw.w.items():
+            if n in ("in_layer.0.weight", "cond_layer.0.weight", "time_emb.mlp.0.weight"):
+                continue
+            rows, cols = w.shape        # [out, in(padded)]
+            self.wT[n] = torch.empty((cols, ops.round_up(rows, 64)), device=dev, dtype=self.tdt)
+        self.refresh_weights(pack=False)
+        self._acts = {}
+
+    def refresh_weights(self, pack=True):
+        if pack:
+            self.pw.refresh()
+        for n, wt in self.wT.items():
+            w = self.pw.w[n]
+            ops.transpose(w, out=wt, rows_pad=wt.shape[1])
+
+    def bucket_ranges(self):
+        return bucket_ranges(self.offs, self.total, self.depth)
+
+    # ------------------------------------------------------------------ buffers for a batch of C rows
+    def acts(self, C):
+        a = self._acts.get(C)
+        if a is not None:
+            return a
+        H, G, Gp, D, dev, T = self.H, self.G, self.Gp, self.depth, self.device, self.tdt
+        Cp = ops.round_up(C, 64)
+        f32 = torch.float32
+
+        def z(*s, dt=T):
+            return torch.zeros(s, device=dev, dtype=dt)
+        a = dict(
+            C=C, Cp=Cp, cu=torch.tensor([0, C], dtype=torch.int32, device=dev),
+            xp=z(C, Gp), yp=z(C, Gp), e0=z(C, 256), a1=z(C, H), e1=z(C, H), temb=z(C, H, dt=f32), c=z(C, H, dt=f32),
+            s=z(C, H), h=[z(C, H, dt=f32) for _ in range(D + 1)], hmid=[z(C, H, dt=f32) for _ in range(D)],
+            mod=[z(C, 6 * H) for _ in range(D)], xn1=[z(C, H) for _ in range(D)], xn2=[z(C, H) for _ in range(D)],
+            qkv=[z(C, 3 * H) for _ in range(D)], o=[z(C, H) for _ in range(D)], lse=[z(C, self.heads, dt=f32) for _ in range(D)],
+            pa=[z(C, H) for _ in range(D)], pm=[z(C, H) for _ in range(D)], upre=[z(C, 4 * H) for _ in range(D)],
+            u=[z(C, 4 * H) for _ in range(D)],
+            mean1=[z(C, dt=f32) for _ in range(D)], rstd1=[z(C, dt=f32) for _ in range(D)],
+            mean2=[z(C, dt=f32) for _ in range(D)], rstd2=[z(C, dt=f32) for _ in range(D)],
+            fmod=z(C, 2 * H), xnf=z(C, H), meanf=z(C, dt=f32), rstdf=z(C, dt=f32), eps=z(C, G, dt=f32),
+            # backward scratch
+            deps=z(C, Gp), dh=z(C, H, dt=f32), dxn=z(C, H), dmod=z(C, 6 * H), dfmod=z(C, 2 * H), dbr=z(C, H),
+            du=z(C, 4 * H), dupre=z(C, 4 * H), do=z(C, H), dqkv=z(C, 3 * H), delta=z(C, self.heads, dt=f32),
+            ds32=z(C, H, dt=f32), dc=z(C, H, dt=f32), dcT_=z(C, H), de1=z(C, H), da1=z(C, H), dhT_=z(C, H),
+            tA=z(max(6 * H, Gp), Cp), tB=z(max(4 * H, Gp, 256), Cp), sT=z(H, Cp),
+        )
+        if len(self._acts) > 3:
+            self._acts.clear()
+        self._acts[C] = a
+        return a
+
+    def _lin(self, name):
+        return self.pw.w[name + ".weight"], self.pw.b(name + ".bias")
+
+    # ------------------------------------------------------------------ forward (stDiff_model.py:231-243)
+    def forward(self, a, t):
+        """a['xp'], a['yp'] hold the packed inputs; returns eps fp32 [C, G] (a['eps'])."""
+        H, D = self.H, self.depth
+        g = ops.gemm
+        ops.timestep_embedding(t, self.pw.freqs, out=a["e0"])
+        w, b = self._lin("time_emb.mlp.0")
+        g(a["e0"], w, b, out=a["e1"], epi=L.EPI_SILU, out2=a["a1"])
+        w, b = self._lin("time_emb.mlp.2")
+        g(a["e1"], w, b, out=a["temb"])
+        w, b = self._lin("cond_layer.0")
+        g(a["yp"], w, b, out=a["c"], epi=L.EPI_ADD, res=a["temb"])
+        ops.silu_cond(a["c"], out=a["s"])
+        w, b = self._lin("in_layer.0")
+        g(a["xp"], w, b, out=a["h"][0])
+        for k in range(D):
+            p = f"blks.{k}."
+            mod = a["mod"][k]
+            w, b = self._lin(p + "adaLN_modulation.1")
+            g(a["s"], w, b, out=mod)
+            ops.ln_modulate(a["h"][k], mod[:, 0:H], mod[:, H:2 * H], out=a["xn1"][k], mean=a["mean1"][k], rstd=a["rstd1"][k])
+            w, b = self._lin(p + "attn.qkv")
+            g(a["xn1"][k], w, b, out=a["qkv"][k])
+            ops.attention_fwd(a["qkv"][k], a["cu"], a["C"], self.heads, out=a["o"][k], lse=a["lse"][k])
+            w, b = self._lin(p + "attn.proj")
+            g(a["o"][k], w, b, out=a["hmid"][k], epi=L.EPI_GATE_RES, gate=mod[:, 2 * H:3 * H], res=a["h"][k], out2=a["pa"][k])
+            ops.ln_modulate(a["hmid"][k], mod[:, 3 * H:4 * H], mod[:, 4 * H:5 * H], out=a["xn2"][k], mean=a["mean2"][k],
+                            rstd=a["rstd2"][k])
+            w, b = self._lin(p + "mlp.fc1")
+            g(a["xn2"][k], w, b, out=a["u"][k], epi=L.EPI_GELU_SAVE, out2=a["upre"][k])
+            w, b = self._lin(p + "mlp.fc2")
+            g(a["u"][k], w, b, out=a["h"][k + 1], epi=L.EPI_GATE_RES, gate=mod[:, 5 * H:6 * H], res=a["hmid"][k], out2=a["pm"][k])
+        w, b = self._lin("out_layer.adaLN_modulation.1")
+        g(a["s"], w, b, out=a["fmod"])
+        ops.ln_modulate(a["h"][D], a["fmod"][:, 0:H], a["fmod"][:, H:2 * H], out=a["xnf"], mean=a["meanf"], rstd=a["rstdf"])
+        w, b = self._lin("out_layer.linear")
+        g(a["xnf"], w, b, out=a["eps"])
+        return a["eps"]
+
+    # ------------------------------------------------------------------ backward
+    def _dW(self, a, name, dY, X=None, XT=None, rows=None):
+        """grad[name.weight] = dY^T X ; grad[name.bias] = colsum(dY).  K (= batch rows) zero-padded to Cp."""
+        C, Cp = a["C"], a["Cp"]
+        n_out = dY.shape[1]
+        dYT = ops.transpose(dY, out=a["tA"][:n_out], rows_pad=Cp)
+        if XT is None:
+            XT = ops.transpose(X, out=a["tB"][:X.shape[1]], rows_pad=Cp)
+        gw = self.g[name + ".weight"]
+        m = gw.shape[0] if rows is None else rows
+        ops.gemm(dYT[:m], XT[:gw.shape[1]], None, out=gw)
+        ops.colsum(dY[:, :m] if rows is not None else dY, self.g[name + ".bias"])
+
+    def _dX(self, name, dY, out, epi=L.EPI_BIAS):
+        """out (+)= dY W  via the transposed operand copy W^T [in, out_pad]."""
+        wt = self.wT[name + ".weight"]
+        return ops.gemm(dY, wt[:, :dY.shape[1]] if wt.shape[1] != dY.shape[1] else wt, None, out=out, epi=epi)
+
+    def backward(self, a, after_bucket=None):
+        """a['deps'] holds d loss / d eps as the packed operand [C, Gp]; fills self.flat_g (overwrite).
+        after_bucket(i) is called when the i-th range of bucket_ranges() is final (DDP overlap)."""
+        H, D = self.H, self.depth
+        Cp = a["Cp"]
+        deps = a["deps"]
+        # ---- final layer
+        self._dW(a, "out_layer.linear", deps, X=a["xnf"], rows=self.G)
+        self._dX("out_layer.linear", deps, a["dxn"])
+        ops.ln_modulate_bwd(a["dxn"], a["h"][D], a["meanf"], a["rstdf"], a["fmod"][:, H:2 * H], a["dh"],
+                            a["dfmod"][:, 0:H], a["dfmod"][:, H:2 * H], accumulate=False)
+        sT = ops.transpose(a["s"], out=a["sT"], rows_pad=Cp)
+        self._dW(a, "out_layer.adaLN_modulation.1", a["dfmod"], XT=sT)
+        self._dX("out_layer.adaLN_modulation.1", a["dfmod"], a["ds32"])
+        if after_bucket:
+            after_bucket(0)
+        for k in range(D - 1, -1, -1):
+            p = f"blks.{k}."
+            mod, dmod = a["mod"][k], a["dmod"]
+            # MLP branch: h_{k+1} = hmid + gate_mlp * pm
+            ops.gate_bwd(a["dh"], mod[:, 5 * H:6 * H], a["pm"][k], a["dbr"], dmod[:, 5 * H:6 * H])
+            self._dW(a, p + "mlp.fc2", a["dbr"], X=a["u"][k])
+            self._dX(p + "mlp.fc2", a["dbr"], a["du"])
+            ops.gelu_bwd(a["du"], a["upre"][k], a["dupre"])
+            self._dW(a, p + "mlp.fc1", a["dupre"], X=a["xn2"][k])
+            self._dX(p + "mlp.fc1", a["dupre"], a["dxn"])
+            ops.ln_modulate_bwd(a["dxn"], a["hmid"][k], a["mean2"][k], a["rstd2"][k], mod[:, 4 * H:5 * H], a["dh"],
+                                dmod[:, 3 * H:4 * H], dmod[:, 4 * H:5 * H], accumulate=True)
+            # attention branch: hmid = h_k + gate_msa * pa
+            ops.gate_bwd(a["dh"], mod[:, 2 * H:3 * H], a["pa"][k], a["dbr"], dmod[:, 2 * H:3 * H])
+            self._dW(a, p + "attn.proj", a["dbr"], X=a["o"][k])
+            self._dX(p + "attn.proj", a["dbr"], a["do"])
+            ops.attention_bwd(a["qkv"][k], a["o"][k], a["do"], a["lse"][k], a["cu"], a["C"], self.heads,
+                              dqkv=a["dqkv"], delta=a["delta"])
+            self._dW(a, p + "attn.qkv", a["dqkv"], X=a["xn1"][k])
+            self._dX(p + "attn.qkv", a["dqkv"], a["dxn"])
+            ops.ln_modulate_bwd(a["dxn"], a["h"][k], a["mean1"][k], a["rstd1"][k], mod[:, H:2 * H], a["dh"],
+                                dmod[:, 0:H], dmod[:, H:2 * H], accumulate=True)
+            self._dW(a, p + "adaLN_modulation.1", dmod, XT=sT)
+            self._dX(p + "adaLN_modulation.1", dmod, a["ds32"], epi=L.EPI_ACCUM)
+            if after_bucket:
+                after_bucket(D - k)
+        # ---- embeddings: h0 = in_layer(x); c = time_emb(t) + cond_layer(y); s = silu(c)
+        ops.pack_rows(a["dh"], H, self.tdt, out=a["dhT_"])
+        self._dW(a, "in_layer.0", a["dhT_"], X=a["xp"])
+        ops.silu_bwd(a["ds32"], a["c"], a["dc"])
+        ops.pack_rows(a["dc"], H, self.tdt, out=a["dcT_"])
+        self._dW(a, "cond_layer.0", a["dcT_"], X=a["yp"])
+        self._dW(a, "time_emb.mlp.2", a["dcT_"], X=a["e1"])
+        self._dX("time_emb.mlp.2", a["dcT_"], a["de1"])
+        ops.silu_bwd(a["de1"], a["a1"], a["da1"])
+        self._dW(a, "time_emb.mlp.0", a["da1"], X=a["e0"])
+        if after_bucket:
+            after_bucket(D + 1)
+
+
+class TrainEngine(TrainCore):
+    """One reference training iteration per step() (stDiff_train.py:59-81)."""
+
+    def __init__(self, model, lr=1e-4, diffusion_step=1000, mask=None, weight_decay=0.0, betas=(0.9, 0.999),
+                 eps=1e-8, max_norm=1.0, process_group=None):
+        super().__init__(model)
+        from .model.stDiff_scheduler import NoiseScheduler
+        dev = self.device
+        self.T = diffusion_step
+        sched = NoiseScheduler(num_timesteps=diffusion_step, beta_schedule='cosine')      # stDiff_train.py:39-42
+        self.sa = sched.sqrt_alphas_cumprod.to(dev)
+        self.sb = sched.sqrt_one_minus_alphas_cumprod.to(dev)
+        if mask is None:
+            raise TypeError("mask is required (the reference crashes on torch.tensor(None), stDiff_train.py:69)")
+        self.mask = torch.as_tensor(mask, dtype=torch.float32).to(dev).contiguous()
+        self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
+        self.m = torch.zeros_like(self.flat_p)
+        self.v = torch.zeros_like(self.flat_p)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.scal = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            import torch.distributed as dist
+            self.dist = dist
+            self.world = dist.get_world_size(process_group)
+        self.buckets = self.bucket_ranges()
+
+    def step(self, x, x_cond, noise=None, timesteps=None):
+        """x, x_cond: fp32 [C, G] on the device.  Returns (loss[1], grad_norm[1]) device tensors (no host sync)."""
+        C = x.shape[0]
+        dev = self.device
+        a = self.acts(C)
+        if noise is None:
+            noise = torch.randn(x.shape, device=dev)                                   # stDiff_train.py:62
+        if timesteps is None:
+            timesteps = torch.randint(1, self.T, (C,), device=dev).long()              # :63  (t = 0 never drawn)
+        ops.add_noise_splice(x, noise, timesteps, self.sa, self.sb, self.mask, xp=a["xp"])   # :65-70
+        ops.pack_rows(x_cond, self.Gp, self.tdt, out=a["yp"])
+        eps = self.forward(a, timesteps)                                               # :72
+        self.loss.zero_()
+        ops.masked_mse(eps, noise, self.mask, self.loss, dp=a["deps"])                 # :75 (+ d loss / d eps)
+        handles = []
+
+        def reduce_bucket(i):
+            lo, hi = self.buckets[i]
+            handles.append(self.dist.all_reduce(self.flat_g[lo:hi], group=self.pg, async_op=True))
+        self.backward(a, after_bucket=reduce_bucket if self.world > 1 else None)       # :77
+        for h in handles:
+            h.wait()
+        self.sumsq.zero_()
+        ops.grad_sumsq(self.flat_g, self.sumsq)
+        ops.clip_adamw(self.flat_p, self.flat_g, self.m, self.v, self.sumsq, self.step_dev, self.scal, self.lr,
+                       max_norm=self.max_norm, grad_scale=1.0 / self.world, betas=self.betas, eps=self.eps,
+                       weight_decay=self.wd)                                           # :78-80
+        self.refresh_weights()
+        return self.loss, self.scal[3:4]
+
+
+class _DitFunction(torch.autograd.Function):
+    """autograd bridge so that `loss(model(x, t, y)).backward()` works with the hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, core, x, t, y, *params):
+        C = x.shape[0]
+        a = core.acts(C)
+        ops.pack_rows(x, core.Gp, core.tdt, out=a["xp"])
+        ops.pack_rows(y, core.Gp, core.tdt, out=a["yp"])
+        eps = core.forward(a, t)
+        ctx.core, ctx.C = core, C
+        return eps.clone()
+
+    @staticmethod
+    def backward(ctx, d_eps):
+        core = ctx.core
+        a = core.acts(ctx.C)
+        ops.pack_rows(d_eps.contiguous().float(), core.Gp, core.tdt, out=a["deps"])
+        core.backward(a)
+        grads = tuple(core.g[n].clone() for n in core.names)
+        return (None, None, None, None) + grads
+
+
+def dit_forward_autograd(model, eng, x, t, y):
+    core = getattr(model, "_train_core", None)
+    if core is None or core.pw is not model.engine().pw:
+        core = model._train_core = TrainCore(model)
+    params = dict(model.named_parameters())
+    return _DitFunction.apply(core, x, t, y, *[params[n] for n in core.names])
