@@ -1,19 +1,26 @@
 // NT GEMM on the gfx950 matrix cores:  C[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]).
 //
 // Every dense contraction of the denoiser (nn.Linear: stDiff_model.py:18,20,54,56,107,128,132,177,180 and the
-// timm Mlp fc1/fc2) is this one shape: both operands are K-contiguous, so both tiles are staged as [rows][K-slab]
-// and both MFMA fragments are plain 16-byte LDS reads.
+// timm Mlp fc1/fc2), forward and backward, is this one shape: both operands are K-contiguous, so both tiles are
+// staged as [rows][K-slab] and both MFMA fragments are plain 16-byte LDS reads.  MFMA is issued "swapped" (the W
+// fragment as the A operand) so a lane ends up holding 4 CONSECUTIVE n of one m.
 //
-//   block  = 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 = 4 x 4 MFMA tiles of 16 x 16
-//   bf16   : K-slab 64,  v_mfma_f32_16x16x32_bf16, fp32 accumulate
-//   f32    : K-slab 16,  v_mfma_f32_16x16x4_f32  (exact fp32: a k-ordered fmaf chain)
-//   LDS    : 2 x (A tile + W tile), 16-byte slots XOR-swizzled so ds_read_b128 is conflict-free
-//            (tools/lds_conflicts.py); global->register->LDS staging, next slab's loads in flight under the MFMAs
-//   MFMA is issued "swapped" (W fragment as the A operand) so a lane ends up holding 4 CONSECUTIVE n of one m:
-//   the accumulators go to an fp32 LDS image of the C tile with one ds_write_b128 each, and the epilogue
-//   (bias / SiLU / GELU / gate*v+res / ...) then runs on whole 32-byte row pieces with coalesced global traffic.
-//   grid   : 1-D, XCD-aware (blocks b and b+8 share an L2): each XCD walks a contiguous range of tiles, ordered
-//            in groups of 8 row-tiles x all column-tiles so the A panel and the weight panel stay L2-resident.
+// Two kernels:
+//   gemm256p_kernel  bf16, 256 x 256 block tile, 8 waves, LDS-DMA staging, 4 phases per K-slab with counted waits and
+//                    two staggered wave groups (details above the kernel).  Used when the grid fills the chip.
+//   gemm_nt_kernel   bf16 or exact-fp32, 128 x 128 tile, 4 waves, register-staged double buffer, 2 blocks per CU.
+//                    bf16: v_mfma_f32_16x16x32_bf16;  f32: v_mfma_f32_16x16x4_f32 (a k-ordered fp32 fmaf chain).
+// Both send the accumulators through an fp32 LDS image of the C tile so that the epilogue (bias / SiLU / GELU-erf /
+// gate*v+res / +res / accumulate / save-pre-activation) loads and stores whole row pieces, in batches whose latencies
+// overlap.  The epilogue math is a compile-time template parameter dispatched ONCE per block: a runtime switch inside
+// the unrolled store loop replicated the erf/exp code 32x (128 KiB of instructions) and cost 13 us per tile.
+// Grid: 1-D, XCD-aware (blocks b and b+8 share an L2): each XCD walks a contiguous range of tiles, ordered in groups
+// of 8 row-tiles x all column-tiles so the A panel and the weight panel stay L2-resident.
+#include <math.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -41,7 +48,7 @@ struct Params {
     const void* gate; int ldgate;
     const float* res; int ldres;
     void* C2; int ldc2;
-    int vec;  // all epilogue pointers/strides allow 8-wide vector access
+    int vec;  // every epilogue pointer / stride allows aligned 4-wide (16 B fp32, 8 B bf16) access and N % 8 == 0
     int tiles_m, tiles_n;
 };
 
@@ -58,92 +65,108 @@ __device__ __forceinline__ void tile_of(int bid, int nblk, int tiles_m, int tile
     tn = in / gsz;
 }
 
+// ---------------------------------------------------------------- epilogue pieces (4 consecutive columns of one row)
+template <int EPI> __device__ __forceinline__ f32x4 epi_math(f32x4 pre, f32x4 g, f32x4 r) {
+    f32x4 o;
+    if constexpr (EPI == STDIFF_EPI_SILU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = silu_f(pre[j]);
+    } else if constexpr (EPI == STDIFF_EPI_GELU || EPI == STDIFF_EPI_GELU_SAVE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = gelu_erf_f(pre[j]);
+    } else if constexpr (EPI == STDIFF_EPI_GATE_RES) {
+        o = r + g * pre;
+    } else if constexpr (EPI == STDIFF_EPI_ADD || EPI == STDIFF_EPI_ACCUM) {
+        o = pre + r;
+    } else {
+        o = pre;
+    }
+    return o;
+}
+
+// aligned side loads for one piece (row / column already clamped into range by the caller)
+template <int EPI, typename T>
+__device__ __forceinline__ void epi_load(const Params& p, int gm, int gn, f32x4& g, f32x4& r) {
+    if constexpr (EPI == STDIFF_EPI_GATE_RES) g = ld4((const T*)p.gate + (size_t)gm * p.ldgate + gn);
+    if constexpr (EPI == STDIFF_EPI_GATE_RES || EPI == STDIFF_EPI_ADD) r = *(const f32x4*)(p.res + (size_t)gm * p.ldres + gn);
+    if constexpr (EPI == STDIFF_EPI_ACCUM) r = *(const f32x4*)((const float*)p.C + (size_t)gm * p.ldc + gn);
+}
+
+template <int EPI, typename T>
+__device__ __forceinline__ void epi_store(const Params& p, int gm, int gn, f32x4 pre, f32x4 g, f32x4 r) {
+    const f32x4 o = epi_math<EPI>(pre, g, r);
+    if (p.c_bf16) st4((bf16_t*)p.C + (size_t)gm * p.ldc + gn, o);
+    else *(f32x4*)((float*)p.C + (size_t)gm * p.ldc + gn) = o;
+    if (p.C2) st4((T*)p.C2 + (size_t)gm * p.ldc2 + gn, pre);       // v itself, in the operand dtype
+}
+
+// any alignment, ragged N: scalar, runtime epilogue; callers keep it inside `#pragma unroll 1` loops so the code
+// exists once (odd shapes only, e.g. G = 33 genes)
 template <typename T>
-__device__ __forceinline__ void epilogue8(const Params& p, int gm, int gn, const float* v) {
-    float o[8];
-    float pre[8];
+__device__ __forceinline__ void epilogue4_slow(const Params& p, int gm, int gn, f32x4 v) {
+#pragma unroll 1
+    for (int j = 0; j < 4; ++j) {
+        const int n = gn + j;
+        if (n >= p.N) return;
+        const float pre = v[j] + (p.bias ? p.bias[n] : 0.f);
+        float o;
+        switch (p.epi) {
+            case STDIFF_EPI_SILU: o = silu_f(pre); break;
+            case STDIFF_EPI_GELU:
+            case STDIFF_EPI_GELU_SAVE: o = gelu_erf_f(pre); break;
+            case STDIFF_EPI_GATE_RES:
+                o = p.res[(size_t)gm * p.ldres + n] + Elem<T>::ld((const T*)p.gate + (size_t)gm * p.ldgate + n) * pre;
+                break;
+            case STDIFF_EPI_ADD: o = pre + p.res[(size_t)gm * p.ldres + n]; break;
+            case STDIFF_EPI_ACCUM: o = pre + ((const float*)p.C)[(size_t)gm * p.ldc + n]; break;
+            default: o = pre;
+        }
+        if (p.c_bf16) ((bf16_t*)p.C)[(size_t)gm * p.ldc + n] = f2bf(o);
+        else ((float*)p.C)[(size_t)gm * p.ldc + n] = o;
+        if (p.C2) Elem<T>::st((T*)p.C2 + (size_t)gm * p.ldc2 + n, pre);
+    }
+}
+
+#define STDIFF_EPI_DISPATCH(CALL)                                  \
+    switch (p.epi) {                                               \
+        case STDIFF_EPI_SILU: CALL(STDIFF_EPI_SILU); break;        \
+        case STDIFF_EPI_GELU:                                      \
+        case STDIFF_EPI_GELU_SAVE: CALL(STDIFF_EPI_GELU); break;   \
+        case STDIFF_EPI_GATE_RES: CALL(STDIFF_EPI_GATE_RES); break; \
+        case STDIFF_EPI_ADD: CALL(STDIFF_EPI_ADD); break;          \
+        case STDIFF_EPI_ACCUM: CALL(STDIFF_EPI_ACCUM); break;      \
+        default: CALL(STDIFF_EPI_BIAS); break;                     \
+    }
+
+// ================================================================ 128 x 128 kernel (bf16 / fp32)
+// rows of the fp32 C image `cl` [128][CLD] -> global: thread = 8 columns (two pieces) of rows (tid>>4) + 16*pass
+template <int EPI, typename T>
+__device__ __forceinline__ void epi_rows128(const Params& p, const float* cl, int tid, int m0, int n0) {
+    const int c8 = (tid & 15) * 8, r0 = tid >> 4;
+    const int gn = n0 + c8;
+    if (gn >= p.N) return;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (p.bias) { b0 = *(const f32x4*)(p.bias + gn); b1 = *(const f32x4*)(p.bias + gn + 4); }
+#pragma unroll 1
+    for (int pb = 0; pb < 2; ++pb) {
+        f32x4 g[4][2], r[4][2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) pre[j] = v[j];
-    if (p.bias) {
-        if (p.vec) {
-            f32x4 b0 = *(const f32x4*)(p.bias + gn), b1 = *(const f32x4*)(p.bias + gn + 4);
+        for (int ps = 0; ps < 4; ++ps) {
+            const int gm = min(m0 + r0 + 16 * (pb * 4 + ps), p.M - 1);
+            epi_load<EPI, T>(p, gm, gn, g[ps][0], r[ps][0]);
+            epi_load<EPI, T>(p, gm, gn + 4, g[ps][1], r[ps][1]);
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { pre[j] += b0[j]; pre[4 + j] += b1[j]; }
-        } else {
-            for (int j = 0; j < 8; ++j) if (gn + j < p.N) pre[j] += p.bias[gn + j];
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = r0 + 16 * (pb * 4 + ps), gm = m0 + row;
+            if (gm < p.M) {
+                const f32x4 v0 = *(const f32x4*)(cl + row * CLD + c8) + b0;
+                const f32x4 v1 = *(const f32x4*)(cl + row * CLD + c8 + 4) + b1;
+                epi_store<EPI, T>(p, gm, gn, v0, g[ps][0], r[ps][0]);
+                epi_store<EPI, T>(p, gm, gn + 4, v1, g[ps][1], r[ps][1]);
+            }
         }
     }
-    switch (p.epi) {
-        case STDIFF_EPI_SILU:
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = silu_f(pre[j]);
-            break;
-        case STDIFF_EPI_GELU:
-        case STDIFF_EPI_GELU_SAVE:
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = gelu_erf_f(pre[j]);
-            break;
-        case STDIFF_EPI_GATE_RES: {
-            const T* g = (const T*)p.gate + (size_t)gm * p.ldgate + gn;
-            const float* r = p.res + (size_t)gm * p.ldres + gn;
-            if (p.vec) {
-                f32x4 g0 = ld4(g), g1 = ld4(g + 4), r0 = *(const f32x4*)r, r1 = *(const f32x4*)(r + 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { o[j] = r0[j] + g0[j] * pre[j]; o[4 + j] = r1[j] + g1[j] * pre[4 + j]; }
-            } else {
-                for (int j = 0; j < 8; ++j) o[j] = (gn + j < p.N) ? r[j] + Elem<T>::ld(g + j) * pre[j] : 0.f;
-            }
-            break;
-        }
-        case STDIFF_EPI_ADD: {
-            const float* r = p.res + (size_t)gm * p.ldres + gn;
-            if (p.vec) {
-                f32x4 r0 = *(const f32x4*)r, r1 = *(const f32x4*)(r + 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { o[j] = pre[j] + r0[j]; o[4 + j] = pre[4 + j] + r1[j]; }
-            } else {
-                for (int j = 0; j < 8; ++j) o[j] = (gn + j < p.N) ? pre[j] + r[j] : 0.f;
-            }
-            break;
-        }
-        case STDIFF_EPI_ACCUM: {
-            const float* r = (const float*)p.C + (size_t)gm * p.ldc + gn;
-            if (p.vec) {
-                f32x4 r0 = *(const f32x4*)r, r1 = *(const f32x4*)(r + 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { o[j] = pre[j] + r0[j]; o[4 + j] = pre[4 + j] + r1[j]; }
-            } else {
-                for (int j = 0; j < 8; ++j) o[j] = (gn + j < p.N) ? pre[j] + r[j] : 0.f;
-            }
-            break;
-        }
-        default:
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = pre[j];
-    }
-    auto store = [&](void* base, int ld, const float* w, bool bf) {
-        if (bf) {
-            bf16_t* c = (bf16_t*)base + (size_t)gm * ld + gn;
-            if (p.vec) {
-                u32x4 pk;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) pk[j] = (unsigned)f2bf(w[2 * j]) | ((unsigned)f2bf(w[2 * j + 1]) << 16);
-                *(u32x4*)c = pk;
-            } else {
-                for (int j = 0; j < 8; ++j) if (gn + j < p.N) c[j] = f2bf(w[j]);
-            }
-        } else {
-            float* c = (float*)base + (size_t)gm * ld + gn;
-            if (p.vec) {
-                *(f32x4*)c = f32x4{w[0], w[1], w[2], w[3]};
-                *(f32x4*)(c + 4) = f32x4{w[4], w[5], w[6], w[7]};
-            } else {
-                for (int j = 0; j < 8; ++j) if (gn + j < p.N) c[j] = w[j];
-            }
-        }
-    };
-    store(p.C, p.ldc, o, p.c_bf16);
-    if (p.C2) store(p.C2, p.ldc2, pre, sizeof(T) == 2);   // pre-activation v, kept in the operand dtype
 }
 
 template <typename T>
@@ -258,15 +281,224 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
             *(f32x4*)(cl + m * CLD + n) = acc[mt][nt];
         }
     __syncthreads();
-    const int c8 = (tid & 15) * 8;
+    if (p.vec) {
+#define STDIFF_CALL128(E) epi_rows128<E, T>(p, cl, tid, m0, n0)
+        STDIFF_EPI_DISPATCH(STDIFF_CALL128)
+        return;
+    }
+#pragma unroll 1
+    for (int i = 0; i < 16; ++i) {
+        const int r = (tid >> 4) + 16 * (i >> 1), c4 = (tid & 15) * 8 + 4 * (i & 1);
+        const int gm = m0 + r, gn = n0 + c4;
+        if (gm < p.M && gn < p.N) epilogue4_slow<T>(p, gm, gn, *(const f32x4*)(cl + r * CLD + c4));
+    }
+}
+
+// ================================================================ bf16, 256 x 256 tile, 4 phases per K-slab, counted DMA waits
+// One workgroup per CU, 8 waves as 2 (M) x 4 (N).  The tile is cut into half-tiles A0/A1 (rows 0-127 / 128-255 of the
+// block) and B0/B1 (columns); wave (wr, wc) owns rows {128*mh + 64*wr + 0..63} and columns {128*nh + 32*wc + 0..31}
+// for mh, nh in {0,1}, so in phase (mh, nh) EVERY wave reads half-tiles A_mh and B_nh only:
+//     Q1 = (A0,B0)   Q2 = (A0,B1)   Q3 = (A1,B1)   Q4 = (A1,B0)        16 MFMAs (64 x 32 x K64) per wave per phase
+// A half-tile therefore retires early (A0 after Q2, B1 after Q3, A1/B0 after Q4) and is refilled by LDS-DMA
+// (global_load_lds, 16 B per lane, 1 KiB = 8 rows per wave-instruction, no VGPR round trip) two phases later, ONE
+// half-tile (2 instructions per lane) per phase:
+//     t.Q1: B1(t+1)   t.Q2: B0(t+1)   t.Q3: A1(t+1)   t.Q4: A0(t+2)
+// so up to 3 half-tiles stay in flight across the barriers.  The LDS image is lane-linear, so the XOR slot swizzle is
+// applied to the per-lane SOURCE address and to the fragment read (cdna guide 5.4 rule 21).  Waits are counted, never
+// vmcnt(0) in steady state: vmcnt(6) in Q2 (retires A1(t), read in Q3) and vmcnt(4) in Q4 (retires A0,B1,B0 of t+1,
+// read from the next Q1 on); each wait sits before that phase's barrier and the data is read one phase later.
+// Waves 4-7 (wr = 1) run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA cluster while its
+// partner reads fragments / issues DMA.  Two barriers per phase; restage >= 2 phases after the last read, read >= 1
+// phase after the wait.  Measured per 256x256x64 slab: 1.46 us (1.47 PFLOP/s chip-wide at K = 1024).
+#define STDIFF_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define STDIFF_BARRIER()               \
+    do {                               \
+        __builtin_amdgcn_s_barrier();  \
+        asm volatile("" ::: "memory"); \
+    } while (0)
+
+// rows of the swizzled fp32 C half image `cl` [128][256] -> global; thread = column chunks (tid&31) and +32 of
+// rows (tid>>5) + 16*pass: every wave-instruction covers 2 whole 256-column rows
+template <int EPI>
+__device__ __forceinline__ void epi_rows256(const Params& p, const float* cl, int tid, int m0, int n0, int mh) {
+    const int rl = tid >> 5, cq = tid & 31;
+    int gnc[2];
+    f32x4 bias4[2];
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-        int r = (tid >> 4) + 16 * ps;
-        int gm = m0 + r, gn = n0 + c8;
-        if (gm < p.M && gn < p.N) {
-            f32x4 v0 = *(const f32x4*)(cl + r * CLD + c8), v1 = *(const f32x4*)(cl + r * CLD + c8 + 4);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            epilogue8<T>(p, gm, gn, v);
+    for (int h = 0; h < 2; ++h) {
+        gnc[h] = min(n0 + (cq + 32 * h) * 4, p.N - 4);
+        bias4[h] = p.bias ? *(const f32x4*)(p.bias + gnc[h]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll 1
+    for (int pb = 0; pb < 2; ++pb) {
+        f32x4 g[4][2], r[4][2];
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int gm = min(m0 + mh * 128 + (pb * 4 + ps) * 16 + rl, p.M - 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) epi_load<EPI, bf16_t>(p, gm, gnc[h], g[ps][h], r[ps][h]);
+        }
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = (pb * 4 + ps) * 16 + rl, gm = m0 + mh * 128 + row;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int gn = n0 + (cq + 32 * h) * 4;
+                if (gm < p.M && gn < p.N) {
+                    const f32x4 pre = *(const f32x4*)(cl + row * 256 + (((cq + 32 * h) ^ (row & 15)) << 2)) + bias4[h];
+                    epi_store<EPI, bf16_t>(p, gm, gn, pre, g[ps][h], r[ps][h]);
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void gemm256p_kernel(Params p) {
+    constexpr int ROWB = 128, HALF = 128 * ROWB;          // one half-tile = 128 rows x 64 bf16 = 16 KiB
+    __shared__ __attribute__((aligned(16))) unsigned char smem[8 * HALF];   // [buf][A0 A1 B0 B1]
+
+    int tm, tn;
+    tile_of(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    // DMA sources: half-tile h, piece q = 2*wid + i (8 rows): lane -> row 8q + (lane>>3), LDS slot lane&7
+    const bf16_t* src[4][2];       // [A0 A1 B0 B1][piece]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (2 * wid + i) * 8 + (lane >> 3);
+            const int sw = ((lane & 7) ^ (row & 7)) << 3;
+            src[h][i] = (const bf16_t*)p.A + (size_t)min(m0 + h * 128 + row, p.M - 1) * p.lda + sw;
+            src[2 + h][i] = (const bf16_t*)p.W + (size_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw + sw;
+        }
+    auto dma = [&](int buf, int slot, int kt) {       // half-tile `slot` of K-slab kt into buffer buf
+        unsigned char* dst = smem + (buf * 4 + slot) * HALF + (2 * wid) * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[slot][i] + kt * 64),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    };
+
+    // fragment read offsets inside a half-tile (row & 7 == fr & 7 for every fragment row)
+    int offA[2], offB[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int sl = ((ks * 4 + fq) ^ (fr & 7)) << 4;
+        offA[ks] = (wr * 64 + fr) * ROWB + sl;
+        offB[ks] = (wc * 32 + fr) * ROWB + sl;
+    }
+    bf16x8 af[4][2], bfr[2][2];
+    auto loadA = [&](int buf, int mh) {
+        const unsigned char* b = smem + (buf * 4 + mh) * HALF;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[mt][ks] = *(const bf16x8*)(b + offA[ks] + mt * 16 * ROWB);
+    };
+    auto loadB = [&](int buf, int nh) {
+        const unsigned char* b = smem + (buf * 4 + 2 + nh) * HALF;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bfr[nt][ks] = *(const bf16x8*)(b + offB[ks] + nt * 16 * ROWB);
+    };
+
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define STDIFF_MMA(MH, NH)                                                                                    \
+    do {                                                                                                      \
+        __builtin_amdgcn_s_setprio(1);                                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                      \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                      \
+            acc[MH][NH][mt][nt] =                                                                             \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt][ks], af[mt][ks], acc[MH][NH][mt][nt], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
+    } while (0)
+
+    const int nk = p.K / 64;
+    // prologue: slab 0 complete + A0 of slab 1 in flight
+    dma(0, 0, 0); dma(0, 2, 0); dma(0, 3, 0); dma(0, 1, 0);
+    if (nk > 1) { dma(1, 0, 1); STDIFF_VMCNT(2); } else { STDIFF_VMCNT(0); }
+    STDIFF_BARRIER();
+    if (wr == 1) STDIFF_BARRIER();                 // stagger the second wave group by one barrier
+
+    for (int t = 0; t < nk; ++t) {
+        const int b = t & 1, nb = b ^ 1;
+        const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+        // ---- Q1 (A0, B0)
+        loadB(b, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        loadA(b, 0);
+        if (n1) dma(nb, 3, t + 1);                 // B1(t+1)
+        STDIFF_BARRIER();
+        STDIFF_MMA(0, 0);
+        STDIFF_BARRIER();
+        // ---- Q2 (A0, B1)
+        loadB(b, 1);
+        if (n1) { dma(nb, 2, t + 1); STDIFF_VMCNT(6); } else { STDIFF_VMCNT(0); }     // B0(t+1); retire A1(t)
+        STDIFF_BARRIER();
+        STDIFF_MMA(0, 1);
+        STDIFF_BARRIER();
+        // ---- Q3 (A1, B1)
+        loadA(b, 1);
+        if (n1) dma(nb, 1, t + 1);                 // A1(t+1)
+        STDIFF_BARRIER();
+        STDIFF_MMA(1, 1);
+        STDIFF_BARRIER();
+        // ---- Q4 (A1, B0)
+        loadB(b, 0);
+        if (n2) { dma(b, 0, t + 2); STDIFF_VMCNT(4); } else if (n1) { STDIFF_VMCNT(2); }   // A0(t+2); retire A0,B1,B0(t+1)
+        STDIFF_BARRIER();
+        STDIFF_MMA(1, 0);
+        STDIFF_BARRIER();
+    }
+    if (wr == 0) STDIFF_BARRIER();                 // balance the stagger
+
+    // the block's C half (128 rows x 256 cols fp32 = all 128 KiB of LDS), XOR-swizzled 16-byte chunks
+    float* cl = (float*)smem;
+    auto put = [&](auto MH) {
+        constexpr int mh = decltype(MH)::value;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int row = wr * 64 + mt * 16 + fr;
+                    const int chunk = (nh * 128 + wc * 32 + nt * 16 + fq * 4) >> 2;
+                    *(f32x4*)(cl + row * 256 + ((chunk ^ (row & 15)) << 2)) = acc[mh][nh][mt][nt];
+                }
+    };
+#pragma unroll 1
+    for (int mh = 0; mh < 2; ++mh) {
+        __syncthreads();
+        if (mh == 0) put(std::integral_constant<int, 0>{}); else put(std::integral_constant<int, 1>{});
+        __syncthreads();
+        if (p.vec) {
+#define STDIFF_CALL256(E) epi_rows256<E>(p, cl, tid, m0, n0, mh)
+            STDIFF_EPI_DISPATCH(STDIFF_CALL256)
+        } else {
+#pragma unroll 1
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i >> 1) * 16 + (tid >> 5), ch = (tid & 31) + 32 * (i & 1);
+                const int gm = m0 + mh * 128 + row, gn = n0 + ch * 4;
+                if (gm < p.M && gn < p.N)
+                    epilogue4_slow<bf16_t>(p, gm, gn, *(const f32x4*)(cl + row * 256 + ((ch ^ (row & 15)) << 2)));
+            }
         }
     }
 }
@@ -290,6 +522,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* in, int ldi, T*
 }
 
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+inline bool al8(const void* p) { return ((uintptr_t)p & 7) == 0; }
 
 }  // namespace
 
@@ -309,6 +542,7 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
     if (a->epi == STDIFF_EPI_ADD) STDIFF_CHECK_ARG(a->res != nullptr);
     if (a->epi == STDIFF_EPI_ACCUM) STDIFF_CHECK_ARG(a->c_dtype == STDIFF_F32);
     if (a->epi == STDIFF_EPI_GELU_SAVE) STDIFF_CHECK_ARG(a->C2 != nullptr);
+    if (a->C2) STDIFF_CHECK_ARG(a->ldc2 >= a->N);
 
     Params p;
     p.M = a->M; p.N = a->N; p.K = a->K;
@@ -316,20 +550,37 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
     p.C = a->C; p.ldc = a->ldc; p.c_bf16 = a->c_dtype == STDIFF_BF16;
     p.epi = a->epi; p.gate = a->gate; p.ldgate = a->ldgate; p.res = a->res; p.ldres = a->ldres;
     p.C2 = a->C2; p.ldc2 = a->ldc2;
-    const int cel = p.c_bf16 ? 8 : 4;  // elements per 16 B of the output
-    bool vec = a->N % 8 == 0 && al16(a->C) && a->ldc % cel == 0 && (!a->bias || al16(a->bias));
+    // 4-wide pieces: fp32 needs 16-byte, bf16 8-byte alignment of every row piece
+    bool vec = a->N % 8 == 0 && a->ldc % 4 == 0 && (p.c_bf16 ? al8(a->C) : al16(a->C)) && (!a->bias || al16(a->bias));
     if (a->epi == STDIFF_EPI_GATE_RES)
-        vec = vec && al16(a->gate) && a->ldgate % epv == 0 && al16(a->res) && a->ldres % 4 == 0;
+        vec = vec && a->ldgate % 4 == 0 && (bf ? al8(a->gate) : al16(a->gate)) && al16(a->res) && a->ldres % 4 == 0;
     if (a->epi == STDIFF_EPI_ADD) vec = vec && al16(a->res) && a->ldres % 4 == 0;
-    if (a->C2) vec = vec && al16(a->C2) && a->ldc2 % epv == 0 && a->ldc2 >= a->N;
+    if (a->C2) vec = vec && a->ldc2 % 4 == 0 && (bf ? al8(a->C2) : al16(a->C2));
     p.vec = vec;
-    p.tiles_m = cdiv(a->M, BM);
-    p.tiles_n = cdiv(a->N, BN);
-    dim3 grid(p.tiles_m * p.tiles_n), block(NT);
-    if (bf)
+
+    // tile choice (bf16): the 256 x 256 pipelined kernel (1 block/CU) when its grid keeps the chip busy
+    const char* fenv = getenv("STDIFF_GEMM_TILE");      // 1 / 3 force a kernel (tests, A/B timing)
+    const int forced = fenv ? atoi(fenv) : 0;
+    // Measured at M = 20000, K = 1024 (profiles/): the 256x256 kernel delivers ~1.43x the per-output rate of the
+    // 128x128 one, but runs ONE block per CU, so its grid is quantised in rounds of 256 tiles; the 128x128 kernel
+    // (2 blocks per CU, short blocks) degrades smoothly.
+    int tile = 1;
+    if (bf && a->M > 128 && a->N > 128) {
+        const double b256 = (double)cdiv(a->M, 256) * cdiv(a->N, 256), b128 = (double)cdiv(a->M, 128) * cdiv(a->N, 128);
+        const double c256 = ceil(b256 / 256.0) * 2.0, c128 = fmax(1.0, b128 / 512.0) / (a->K >= 2048 ? 0.60 : 0.70);
+        tile = c256 <= c128 ? 3 : 1;
+    }
+    if (bf && (forced == 1 || forced == 3)) tile = forced;
+    const int bm = tile == 1 ? BM : 256, bn = tile == 1 ? BN : 256;
+    p.tiles_m = cdiv(a->M, bm);
+    p.tiles_n = cdiv(a->N, bn);
+    dim3 grid(p.tiles_m * p.tiles_n), block(tile == 1 ? NT : 512);
+    if (!bf)
+        hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
+    else if (tile == 1)
         hipLaunchKernelGGL(gemm_nt_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);
     else
-        hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(gemm256p_kernel, grid, block, 0, (hipStream_t)stream, p);
     STDIFF_LAUNCH_STATUS();
     return STDIFF_OK;
 }
