@@ -61,6 +61,24 @@ __device__ __forceinline__ void st4(bf16_t* p, f32x4 v) {
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 __device__ __forceinline__ float gelu_erf_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
+// GELU(erf) for bf16 OUTPUTS, 4 lanes at a time, no transcendentals (packs into v_pk_fma_f32): Phi(x) = 0.5 + xc*Q(u),
+// xc = clamp(x, -5, 5), u = 2*xc^2/25 - 1, Q = degree-12 minimax fit (tools/fit_gelu.py).  |Phi - exact| <= 2.6e-7,
+// |gelu - exact| <= 1.3e-6 on [-5, 5] and <= 1.5e-6*|x|/5 beyond: 3 orders below a bf16 ulp of the result scale.
+__device__ __forceinline__ f32x4 gelu_poly4(f32x4 x) {
+    constexpr float c[13] = {1.413637847e-01f, -7.029628009e-02f, 5.152052268e-02f, -4.044260830e-02f,
+                             3.144217283e-02f, -2.326865308e-02f, 1.640217379e-02f, -1.116433926e-02f,
+                             6.410510279e-03f, -2.685575048e-03f, 1.722799498e-03f, -1.613265136e-03f,
+                             6.087272777e-04f};
+    f32x4 xc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xc[j] = __builtin_amdgcn_fmed3f(x[j], -5.0f, 5.0f);
+    const f32x4 u = xc * xc * 0.08f - 1.0f;
+    f32x4 q = u * c[12] + c[11];
+#pragma unroll
+    for (int k = 10; k >= 0; --k) q = q * u + c[k];
+    return x * (xc * q + 0.5f);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

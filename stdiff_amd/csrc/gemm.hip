@@ -66,9 +66,11 @@ __device__ __forceinline__ void tile_of(int bid, int nblk, int tiles_m, int tile
 }
 
 // ---------------------------------------------------------------- epilogue pieces (4 consecutive columns of one row)
-template <int EPI> __device__ __forceinline__ f32x4 epi_math(f32x4 pre, f32x4 g, f32x4 r) {
+template <int EPI, bool FAST = false> __device__ __forceinline__ f32x4 epi_math(f32x4 pre, f32x4 g, f32x4 r) {
     f32x4 o;
-    if constexpr (EPI == STDIFF_EPI_SILU) {
+    if constexpr (FAST && (EPI == STDIFF_EPI_GELU || EPI == STDIFF_EPI_GELU_SAVE)) {
+        o = gelu_poly4(pre);            // bf16 result: the polynomial's 1.3e-6 is far below the output rounding
+    } else if constexpr (EPI == STDIFF_EPI_SILU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = silu_f(pre[j]);
     } else if constexpr (EPI == STDIFF_EPI_GELU || EPI == STDIFF_EPI_GELU_SAVE) {
@@ -317,71 +319,98 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
         asm volatile("" ::: "memory"); \
     } while (0)
 
-// rows of the swizzled fp32 C half image `cl` [128][256] -> global; thread = column chunks (tid&31) and +32 of
-// rows (tid>>5) + 16*pass: every wave-instruction covers 2 whole 256-column rows
-template <int EPI>
-__device__ __forceinline__ void epi_rows256(const Params& p, const float* cl, int tid, int m0, int n0, int mh) {
-    const int rl = tid >> 5, cq = tid & 31;
-    int gnc[2];
-    f32x4 bias4[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        gnc[h] = min(n0 + (cq + 32 * h) * 4, p.N - 4);
-        bias4[h] = p.bias ? *(const f32x4*)(p.bias + gnc[h]) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+#define STDIFF_LGKMCNT0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// 64 rows of the swizzled fp32 C quarter image `cl` [64][256] -> global.  Image row i = 32*wr + 16*j + fr holds block
+// row 128*mh + 64*wr + 16*(2*mp + j) + fr (quarter q = 2*mh + mp); wave w stores image rows w, w+8, ..: every
+// wave-instruction covers one whole 256-column row (1 KiB fp32 / 512 B bf16), the row index is wave-uniform (scalar
+// bounds check), and the 4 LDS reads of a batch are issued together, ahead of the checks.  Output type and the C2
+// copy are compile-time, as the epilogue kind is.
+template <int EPI, bool CBF, bool HASC2>
+__device__ __forceinline__ void epi_quarter256(const Params& p, const float* cl, int w, int cq, int m0, int n0, int q) {
+    const int gn = n0 + cq * 4;
+    if (gn >= p.N) return;
+    const f32x4 bias4 = p.bias ? *(const f32x4*)(p.bias + gn) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int rbase = m0 + (q >> 1) * 128 + (q & 1) * 32;
 #pragma unroll 1
     for (int pb = 0; pb < 2; ++pb) {
-        f32x4 g[4][2], r[4][2];
+        f32x4 g[4], r[4], v[4];
+        int gm[4];
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
-            const int gm = min(m0 + mh * 128 + (pb * 4 + ps) * 16 + rl, p.M - 1);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) epi_load<EPI, bf16_t>(p, gm, gnc[h], g[ps][h], r[ps][h]);
+            const int i = w + 8 * (pb * 4 + ps);
+            gm[ps] = rbase + (i >> 5) * 64 + ((i >> 4) & 1) * 16 + (i & 15);
+            epi_load<EPI, bf16_t>(p, min(gm[ps], p.M - 1), gn, g[ps], r[ps]);
         }
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
-            const int row = (pb * 4 + ps) * 16 + rl, gm = m0 + mh * 128 + row;
+            const int i = w + 8 * (pb * 4 + ps);
+            v[ps] = *(const f32x4*)(cl + i * 256 + ((cq ^ (i & 15)) << 2));
+        }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int gn = n0 + (cq + 32 * h) * 4;
-                if (gm < p.M && gn < p.N) {
-                    const f32x4 pre = *(const f32x4*)(cl + row * 256 + (((cq + 32 * h) ^ (row & 15)) << 2)) + bias4[h];
-                    epi_store<EPI, bf16_t>(p, gm, gn, pre, g[ps][h], r[ps][h]);
-                }
+        for (int ps = 0; ps < 4; ++ps) asm volatile("" : "+v"(v[ps]));
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            if (gm[ps] < p.M) {
+                const f32x4 pre = v[ps] + bias4;
+                const f32x4 o = epi_math<EPI, CBF>(pre, g[ps], r[ps]);
+                if constexpr (CBF) st4((bf16_t*)p.C + (size_t)gm[ps] * p.ldc + gn, o);
+                else *(f32x4*)((float*)p.C + (size_t)gm[ps] * p.ldc + gn) = o;
+                if constexpr (HASC2) st4((bf16_t*)p.C2 + (size_t)gm[ps] * p.ldc2 + gn, pre);
             }
         }
     }
 }
 
+// PERSISTENT: the grid is min(tiles, CUs) workgroups and each walks tiles b, b + grid, ...  The LDS holds 9 half-tile
+// slots (144 KiB): [buf0: A0 A1 B0 B1][buf1: A0 A1 B0 B1][extra]; the epilogue's fp32 C image (64 rows at a time) lives
+// in the LAST FOUR slots, so the next tile's prologue (slab 0 into buf0 and A0 of slab 1 into buf1.A0) is issued by
+// LDS-DMA BEFORE the epilogue and lands while the block converts and stores its C tile: block launch, prologue
+// latency and most of the store drain disappear from the per-tile cost.  The epilogue uses raw barriers + lgkmcnt
+// waits (a __syncthreads would wait for the DMA and the global stores as well).
+#ifdef STDIFF_GEMM_STAMPS
+__device__ unsigned long long g_stamps[256 * 8 * 4];
+#define STDIFF_STAMP(k) do { if (tid == 0 && blockIdx.x < 256 && iter < 8) g_stamps[(blockIdx.x * 8 + iter) * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STDIFF_STAMP(k) do {} while (0)
+#endif
 __global__ __launch_bounds__(512, 1) void gemm256p_kernel(Params p) {
     constexpr int ROWB = 128, HALF = 128 * ROWB;          // one half-tile = 128 rows x 64 bf16 = 16 KiB
-    __shared__ __attribute__((aligned(16))) unsigned char smem[8 * HALF];   // [buf][A0 A1 B0 B1]
+    __shared__ __attribute__((aligned(16))) unsigned char smem[9 * HALF];
 
-    int tm, tn;
-    tile_of(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
-    const int m0 = tm * 256, n0 = tn * 256;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 2, wc = wid & 3;
     const int fr = lane & 15, fq = lane >> 4;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nk = p.K / 64;
 
     // DMA sources: half-tile h, piece q = 2*wid + i (8 rows): lane -> row 8q + (lane>>3), LDS slot lane&7
     const bf16_t* src[4][2];       // [A0 A1 B0 B1][piece]
+    auto set_tile = [&](int tile, int& m0, int& n0) {
+        int tm, tn;
+        tile_of(tile, ntiles, p.tiles_m, p.tiles_n, tm, tn);
+        m0 = tm * 256; n0 = tn * 256;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (2 * wid + i) * 8 + (lane >> 3);
-            const int sw = ((lane & 7) ^ (row & 7)) << 3;
-            src[h][i] = (const bf16_t*)p.A + (size_t)min(m0 + h * 128 + row, p.M - 1) * p.lda + sw;
-            src[2 + h][i] = (const bf16_t*)p.W + (size_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw + sw;
-        }
+            for (int i = 0; i < 2; ++i) {
+                const int row = (2 * wid + i) * 8 + (lane >> 3);
+                const int sw = ((lane & 7) ^ (row & 7)) << 3;
+                src[h][i] = (const bf16_t*)p.A + (size_t)min(m0 + h * 128 + row, p.M - 1) * p.lda + sw;
+                src[2 + h][i] = (const bf16_t*)p.W + (size_t)min(n0 + h * 128 + row, p.N - 1) * p.ldw + sw;
+            }
+    };
     auto dma = [&](int buf, int slot, int kt) {       // half-tile `slot` of K-slab kt into buffer buf
         unsigned char* dst = smem + (buf * 4 + slot) * HALF + (2 * wid) * 1024;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[slot][i] + kt * 64),
                                              (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    };
+    auto prologue = [&]() {                           // slab 0 complete + A0 of slab 1
+        dma(0, 0, 0); dma(0, 2, 0); dma(0, 3, 0); dma(0, 1, 0);
+        if (nk > 1) dma(1, 0, 1);
     };
 
     // fragment read offsets inside a half-tile (row & 7 == fr & 7 for every fragment row)
@@ -409,14 +438,6 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(Params p) {
     };
 
     f32x4 acc[2][2][4][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #define STDIFF_MMA(MH, NH)                                                                                    \
     do {                                                                                                      \
@@ -429,77 +450,118 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(Params p) {
         __builtin_amdgcn_s_setprio(0);                                                                        \
     } while (0)
 
-    const int nk = p.K / 64;
-    // prologue: slab 0 complete + A0 of slab 1 in flight
-    dma(0, 0, 0); dma(0, 2, 0); dma(0, 3, 0); dma(0, 1, 0);
-    if (nk > 1) { dma(1, 0, 1); STDIFF_VMCNT(2); } else { STDIFF_VMCNT(0); }
-    STDIFF_BARRIER();
-    if (wr == 1) STDIFF_BARRIER();                 // stagger the second wave group by one barrier
-
-    for (int t = 0; t < nk; ++t) {
-        const int b = t & 1, nb = b ^ 1;
-        const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
-        // ---- Q1 (A0, B0)
-        loadB(b, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        loadA(b, 0);
-        if (n1) dma(nb, 3, t + 1);                 // B1(t+1)
-        STDIFF_BARRIER();
-        STDIFF_MMA(0, 0);
-        STDIFF_BARRIER();
-        // ---- Q2 (A0, B1)
-        loadB(b, 1);
-        if (n1) { dma(nb, 2, t + 1); STDIFF_VMCNT(6); } else { STDIFF_VMCNT(0); }     // B0(t+1); retire A1(t)
-        STDIFF_BARRIER();
-        STDIFF_MMA(0, 1);
-        STDIFF_BARRIER();
-        // ---- Q3 (A1, B1)
-        loadA(b, 1);
-        if (n1) dma(nb, 1, t + 1);                 // A1(t+1)
-        STDIFF_BARRIER();
-        STDIFF_MMA(1, 1);
-        STDIFF_BARRIER();
-        // ---- Q4 (A1, B0)
-        loadB(b, 0);
-        if (n2) { dma(b, 0, t + 2); STDIFF_VMCNT(4); } else if (n1) { STDIFF_VMCNT(2); }   // A0(t+2); retire A0,B1,B0(t+1)
-        STDIFF_BARRIER();
-        STDIFF_MMA(1, 0);
-        STDIFF_BARRIER();
-    }
-    if (wr == 0) STDIFF_BARRIER();                 // balance the stagger
-
-    // the block's C half (128 rows x 256 cols fp32 = all 128 KiB of LDS), XOR-swizzled 16-byte chunks
-    float* cl = (float*)smem;
-    auto put = [&](auto MH) {
-        constexpr int mh = decltype(MH)::value;
+    // C quarter image (slots 5..8), XOR-swizzled 16-byte chunks
+    float* cl = (float*)(smem + 5 * HALF);
+    auto put = [&](auto MH, auto MP) {
+        constexpr int mh = decltype(MH)::value, mp = decltype(MP)::value;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const int row = wr * 64 + mt * 16 + fr;
-                    const int chunk = (nh * 128 + wc * 32 + nt * 16 + fq * 4) >> 2;
-                    *(f32x4*)(cl + row * 256 + ((chunk ^ (row & 15)) << 2)) = acc[mh][nh][mt][nt];
+                    const int row = wr * 32 + j * 16 + fr;
+                    const int chunk = nh * 32 + wc * 8 + nt * 4 + fq;
+                    *(f32x4*)(cl + row * 256 + ((chunk ^ fr) << 2)) = acc[mh][nh][2 * mp + j][nt];
                 }
     };
-#pragma unroll 1
-    for (int mh = 0; mh < 2; ++mh) {
-        __syncthreads();
-        if (mh == 0) put(std::integral_constant<int, 0>{}); else put(std::integral_constant<int, 1>{});
-        __syncthreads();
-        if (p.vec) {
-#define STDIFF_CALL256(E) epi_rows256<E>(p, cl, tid, m0, n0, mh)
-            STDIFF_EPI_DISPATCH(STDIFF_CALL256)
-        } else {
-#pragma unroll 1
-            for (int i = 0; i < 16; ++i) {
-                const int row = (i >> 1) * 16 + (tid >> 5), ch = (tid & 31) + 32 * (i & 1);
-                const int gm = m0 + mh * 128 + row, gn = n0 + ch * 4;
-                if (gm < p.M && gn < p.N)
-                    epilogue4_slow<bf16_t>(p, gm, gn, *(const f32x4*)(cl + row * 256 + ((ch ^ (row & 15)) << 2)));
-            }
+
+    int tile = blockIdx.x, m0, n0;
+    set_tile(tile, m0, n0);
+    prologue();
+    int iter = 0;
+    while (true) {
+        STDIFF_STAMP(0);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        STDIFF_VMCNT(0);
+        STDIFF_BARRIER();
+        STDIFF_STAMP(1);
+        if (wr == 1) STDIFF_BARRIER();                 // stagger the second wave group by one barrier
+
+        for (int t = 0; t < nk; ++t) {
+            const int b = t & 1, nb = b ^ 1;
+            const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+            // ---- Q1 (A0, B0)
+            loadB(b, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            loadA(b, 0);
+            if (n1) dma(nb, 3, t + 1);                 // B1(t+1)
+            STDIFF_BARRIER();
+            STDIFF_MMA(0, 0);
+            STDIFF_BARRIER();
+            // ---- Q2 (A0, B1)
+            loadB(b, 1);
+            if (n1) { dma(nb, 2, t + 1); STDIFF_VMCNT(6); } else { STDIFF_VMCNT(0); }     // B0(t+1); retire A1(t)
+            STDIFF_BARRIER();
+            STDIFF_MMA(0, 1);
+            STDIFF_BARRIER();
+            // ---- Q3 (A1, B1)
+            loadA(b, 1);
+            if (n1) dma(nb, 1, t + 1);                 // A1(t+1)
+            STDIFF_BARRIER();
+            STDIFF_MMA(1, 1);
+            STDIFF_BARRIER();
+            // ---- Q4 (A1, B0)
+            loadB(b, 0);
+            if (n2) { dma(b, 0, t + 2); STDIFF_VMCNT(4); } else if (n1) { STDIFF_VMCNT(2); }   // A0(t+2); retire A0,B1,B0(t+1)
+            STDIFF_BARRIER();
+            STDIFF_MMA(1, 0);
+            STDIFF_BARRIER();
         }
+        if (wr == 0) STDIFF_BARRIER();                 // balance the stagger: every wave is past its last LDS read
+        STDIFF_STAMP(2);
+
+        const int em0 = m0, en0 = n0, next = tile + (int)gridDim.x;
+        if (next < ntiles) {                           // next tile's operands fly in under the epilogue
+            set_tile(next, m0, n0);
+            prologue();
+        }
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+            if (q) STDIFF_BARRIER();                   // image reads of the previous quarter are done
+            switch (q) {
+                case 0: put(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); break;
+                case 1: put(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); break;
+                case 2: put(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); break;
+                default: put(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}); break;
+            }
+            STDIFF_LGKMCNT0();
+            STDIFF_BARRIER();
+            if (p.vec) {
+#define STDIFF_CALL256(E)                                                                  \
+    do {                                                                                   \
+        if (p.c_bf16) {                                                                    \
+            if (p.C2) epi_quarter256<E, true, true>(p, cl, wid, lane, em0, en0, q);        \
+            else epi_quarter256<E, true, false>(p, cl, wid, lane, em0, en0, q);            \
+        } else {                                                                           \
+            if (p.C2) epi_quarter256<E, false, true>(p, cl, wid, lane, em0, en0, q);       \
+            else epi_quarter256<E, false, false>(p, cl, wid, lane, em0, en0, q);           \
+        }                                                                                  \
+    } while (0)
+                STDIFF_EPI_DISPATCH(STDIFF_CALL256)
+            } else {
+                const int rbase = em0 + (q >> 1) * 128 + (q & 1) * 32;
+#pragma unroll 1
+                for (int ps = 0; ps < 8; ++ps) {
+                    const int i = (tid >> 6) + 8 * ps, cq = tid & 63;
+                    const int gm = rbase + (i >> 5) * 64 + ((i >> 4) & 1) * 16 + (i & 15), gn = en0 + cq * 4;
+                    if (gm < p.M && gn < p.N)
+                        epilogue4_slow<bf16_t>(p, gm, gn, *(const f32x4*)(cl + i * 256 + ((cq ^ (i & 15)) << 2)));
+                }
+            }
+            STDIFF_LGKMCNT0();                         // image reads landed before the next put / next tile's DMA
+        }
+        STDIFF_STAMP(3);
+        ++iter;
+        if (next >= ntiles) break;
+        tile = next;
     }
 }
 
@@ -519,6 +581,15 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* in, int ldi, T*
         int c = c0 + i, r = r0 + tx;
         if (r < rows_pad && c < cols) out[(size_t)c * ldo + r] = tile[tx][i];   // rows..rows_pad-1: zeros
     }
+}
+
+inline int cu_count() {      // CUs of the current device (one process drives one GPU model: cached once)
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
 }
 
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
@@ -575,6 +646,7 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
     p.tiles_m = cdiv(a->M, bm);
     p.tiles_n = cdiv(a->N, bn);
     dim3 grid(p.tiles_m * p.tiles_n), block(tile == 1 ? NT : 512);
+    if (tile == 3) grid.x = min((int)grid.x, cu_count());      // persistent: one workgroup per CU walks the tiles
     if (!bf)
         hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
     else if (tile == 1)
@@ -584,6 +656,12 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
     STDIFF_LAUNCH_STATUS();
     return STDIFF_OK;
 }
+
+#ifdef STDIFF_GEMM_STAMPS
+extern "C" int stdiff_debug_gemm_stamps(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(g_stamps));
+}
+#endif
 
 extern "C" int stdiff_transpose(const void* in, int ld_in, void* out, int ld_out, int rows, int cols, int rows_pad,
                                 int dtype, void* stream) {
