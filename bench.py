@@ -94,13 +94,14 @@ def measure_gemm_roofline(eng, ws, dtype, reps=3):
     tfile = os.path.join(ROOT, "profiles", "gemm_traffic.json")      # PMC-derived HBM bytes per launch, if collected
     if os.path.isfile(tfile):
         traffic = json.load(open(tfile)).get(dtype)
-    return {"bound": "mfma", "kernel": "gemm_nt_kernel<%s>" % dtype, "achieved": round(achieved, 1),
+    return {"bound": "mfma", "kernel": "gemm256p_kernel (+ gemm_nt_kernel<bf16> where its grid fits better)" if dtype == "bf16"
+            else "gemm_nt_kernel<float>", "achieved": round(achieved, 1),
             "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK[dtype], 4), "traffic": traffic,
             "launches_per_step": len(launches), "avg_launch_us": round(avg_ms * 1e3, 1),
             "flops_per_launch": flops / len(launches)}
 
 
-def cpu_baseline(rows_chunks=2, steps=2):
+def cpu_baseline(rows_chunks=8, steps=12):
     """The oracle (eager PyTorch fp32 restatement of the reference, oracle/cpu_ref.py) on the host cores, on a bounded
     sample of the same workload: `rows_chunks` chunks of 512 spots x 1000 genes, `steps` reverse steps."""
     from oracle import cpu_ref as O
@@ -136,6 +137,7 @@ def main():
     ap.add_argument("--rows", type=int, default=20000, help="spots per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--lanes", type=int, default=0, help="concurrent chunk groups per GPU (0 = engine default)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,8 +171,8 @@ def main():
             torch.cuda.synchronize()
 
     with torch.no_grad():
-        smp = E.ReverseSampler(eng, sched, lens, gt, gt, mask, seed=1234, row_offset=rank * R,
-                               use_graph=not args.no_graph)
+        smp = E.LanedSampler(eng, sched, lens, gt, gt, mask, seed=1234, row_offset=rank * R,
+                             use_graph=not args.no_graph, lanes=args.lanes or None)
         smp.init()
         ts = list(range(T))[::-1]
         left = [0]
@@ -207,12 +209,13 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: {R} spots x {G} genes per GPU, hidden {H}, depth {DEPTH}, "
                                f"{HEADS} heads, chunks of {BATCH}, cosine T={T}; value = spots / (1000 x measured "
                                f"seconds per reverse step)", "parallelism": f"spot-sharded x{world}, no collective",
-                   "hipgraph": not args.no_graph, "noise": "in-kernel Philox4x32-10"},
+                   "hipgraph": not args.no_graph, "noise": "in-kernel Philox4x32-10",
+                   "lanes_per_gpu": len(smp.parts)},
         "step_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12, 1),
     }
     if rank == 0:
         with torch.no_grad():
-            rec["roofline"] = measure_gemm_roofline(eng, smp.ws, args.dtype)
+            rec["roofline"] = measure_gemm_roofline(eng, eng.workspace(lens, lane=99), args.dtype)
         rec["roofline"]["whole_step_frac"] = round(rec["step_tflops"] / PEAK[args.dtype], 4)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()

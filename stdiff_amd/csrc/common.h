@@ -29,6 +29,14 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 __device__ __forceinline__ float bf2f(bf16_t u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }  // RNE, NaN-safe
 
+// two floats -> packed bf16 pair (RNE), one v_cvt_pk_bf16_f32
+typedef float f32x2_cv __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_cv __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2bf(float a, float b) {
+    f32x2_cv v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_cv));
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
@@ -53,8 +61,8 @@ __device__ __forceinline__ f32x4 ld4(const bf16_t* p) {
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *(f32x4*)p = v; }
 __device__ __forceinline__ void st4(bf16_t* p, f32x4 v) {
     u32x2 r;
-    r[0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-    r[1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+    r[0] = pack2bf(v[0], v[1]);
+    r[1] = pack2bf(v[2], v[3]);
     *(u32x2*)p = r;
 }
 

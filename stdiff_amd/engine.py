@@ -4,6 +4,8 @@ in libstdiff_hip.so."""
 import ctypes as C
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -113,13 +115,15 @@ class DenoiserEngine:
         self.pw = pw
         self._ws = {}
 
-    def workspace(self, chunk_lens):
-        key = tuple(int(c) for c in chunk_lens)
+    def workspace(self, chunk_lens, lane=0):
+        """Cached activation buffers for this chunking; `lane` separates concurrent users of equal chunkings."""
+        lens = tuple(int(c) for c in chunk_lens)
+        key = (lens, int(lane))
         ws = self._ws.get(key)
         if ws is None:
-            if len(self._ws) > 4:
+            if len(self._ws) > 8:
                 self._ws.clear()
-            ws = self._ws[key] = Workspace(self.pw, key)
+            ws = self._ws[key] = Workspace(self.pw, lens)
         return ws
 
     # time_emb(t)  (TimestepEmbedder.forward, stDiff_model.py:82-85) -> fp32 [R,H]
@@ -171,12 +175,12 @@ class ReverseSampler:
     (silu -> denoiser -> DDPM update + splice -> t -= 1) is captured into a hipGraph and replayed."""
 
     def __init__(self, engine, sched, chunk_lens, x_cond, gt, mask, pred_type="noise", row_offset=0, seed=0,
-                 use_graph=True):
+                 use_graph=True, lane=0, x_out=None):
         if pred_type not in ("noise", "x_start"):
             raise NotImplementedError()                                  # stDiff_scheduler.py:125-126
         pw = engine.pw
         self.engine, self.pw = engine, pw
-        self.ws = engine.workspace(chunk_lens)
+        self.ws = engine.workspace(chunk_lens, lane)
         self.T = len(sched)
         self.gt, self.mask = gt, mask
         self.pred_type = 0 if pred_type == "noise" else 1
@@ -185,7 +189,8 @@ class ReverseSampler:
         self.coef = step_coefficients(sched).to(dev)
         self.temb = engine.time_embed(torch.arange(self.T, device=dev, dtype=torch.int64))     # [T,H]
         self.ycond = engine.cond_embed(x_cond)                                                 # [R,H]
-        self.x = torch.empty((self.ws.R, pw.G), device=dev, dtype=torch.float32)
+        self.x = x_out if x_out is not None else torch.empty((self.ws.R, pw.G), device=dev, dtype=torch.float32)
+        assert self.x.shape == (self.ws.R, pw.G) and self.x.is_contiguous() and self.x.dtype == torch.float32
         self.t_dev = torch.zeros((1,), device=dev, dtype=torch.int32)
         self.graph = None
         self._graph_z = None
@@ -234,21 +239,99 @@ class ReverseSampler:
             for _ in timesteps:
                 self._enqueue_step(t_first, z)
             return self.x
-        # the legacy default stream cannot be captured: capture and replay on a stream of our own
+        cur = torch.cuda.current_stream()
+        self._prepare_graph(cur)
+        with torch.cuda.stream(self.stream):
+            for _ in timesteps:
+                self.graph.launch()
+        cur.wait_stream(self.stream)
+        return self.x
+
+    def _prepare_graph(self, cur):
+        """Capture one reverse step on this sampler's own stream (the legacy default stream cannot be captured);
+        afterwards that stream is ordered behind `cur`."""
+        t_first, z = self._t_first, self._z
         if self.stream is None:
             self.stream = torch.cuda.Stream(device=self.pw.device)
-        cur = torch.cuda.current_stream()
         self.stream.wait_stream(cur)
-        with torch.cuda.stream(self.stream):
-            if self.graph is None or self._graph_z != (ptr(z), t_first):
+        if self.graph is None or self._graph_z != (ptr(z), t_first):
+            with torch.cuda.stream(self.stream):
                 g = ops.Graph()
                 g.begin()
                 try:
                     self._enqueue_step(t_first, z)
                 finally:
                     g.end()
-                self.graph, self._graph_z = g, (ptr(z), t_first)
-            for _ in timesteps:
-                self.graph.launch()
-        cur.wait_stream(self.stream)
+            self.graph, self._graph_z = g, (ptr(z), t_first)
+
+
+def default_lanes(chunk_lens):
+    """Concurrent lanes per device: 2 when each lane still fills the chip (STDIFF_LANES overrides)."""
+    env = os.environ.get("STDIFF_LANES")
+    if env:
+        return max(1, min(int(env), len(chunk_lens)))
+    return 2 if len(chunk_lens) >= 8 and sum(chunk_lens) >= 8192 else 1
+
+
+class LanedSampler:
+    """ReverseSampler over `lanes` contiguous groups of chunks, each on its own HIP stream with its own hipGraph.
+
+    Chunks are independent in the reverse loop (sample.py:9-16: the denoiser sees one mini-batch at a time), so the
+    lanes never synchronise.  Two lanes keep the matrix cores busy while the other lane's GEMM epilogue pushes its C
+    tile through the write path, fill the tail of a kernel whose tile count does not divide the CU count, and run
+    the HBM-bound LayerNorm / DDPM-step kernels of one lane under the GEMMs of the other.  Noise is keyed by the
+    GLOBAL row, so the result does not depend on the lane count (tests/test_gpu_model.py)."""
+
+    def __init__(self, engine, sched, chunk_lens, x_cond, gt, mask, pred_type="noise", row_offset=0, seed=0,
+                 use_graph=True, lanes=None):
+        chunk_lens = [int(c) for c in chunk_lens]
+        lanes = default_lanes(chunk_lens) if lanes is None else max(1, min(int(lanes), max(1, len(chunk_lens))))
+        R = sum(chunk_lens)
+        self.x = torch.empty((R, engine.pw.G), device=engine.pw.device, dtype=torch.float32)
+        self.parts = []
+        per, extra, c0, r0 = len(chunk_lens) // lanes, len(chunk_lens) % lanes, 0, 0
+        for i in range(lanes):
+            n = per + (1 if i < extra else 0)
+            lens = chunk_lens[c0:c0 + n]
+            r1 = r0 + sum(lens)
+            self.parts.append(ReverseSampler(engine, sched, lens, x_cond[r0:r1], gt[r0:r1], mask, pred_type=pred_type,
+                                             row_offset=row_offset + r0, seed=seed, use_graph=use_graph, lane=i,
+                                             x_out=self.x[r0:r1]))
+            c0, r0 = c0 + n, r1
+        self.bounds = [(p.row_offset - row_offset, p.row_offset - row_offset + p.ws.R) for p in self.parts]
+        self.use_graph = use_graph
+
+    def init(self, x_T=None):
+        for p, (a, b) in zip(self.parts, self.bounds):
+            p.init(None if x_T is None else x_T[a:b])
+
+    def run(self, timesteps, z=None):
+        if z is not None and len(self.parts) > 1:
+            raise ValueError("injected step noise needs lanes=1 (its layout is [step, all rows, G])")
+        if not timesteps:
+            return self.x
+        t_first = int(timesteps[0])
+        assert list(timesteps) == list(range(t_first, t_first - len(timesteps), -1))
+        for p in self.parts:
+            p.t_dev.fill_(t_first)
+            p._t_first, p._z, p._t_next = t_first, z, t_first
+        return self.run_more(len(timesteps))
+
+    def run_more(self, n):
+        if len(self.parts) == 1 or not self.use_graph:
+            for p in self.parts:
+                p.run_more(n)
+            return self.x
+        cur = torch.cuda.current_stream()
+        for p in self.parts:
+            if n > p._t_next + 1:
+                raise ValueError(f"{n} more steps requested but only {p._t_next + 1} timesteps remain")
+            p._t_next -= n
+            p._prepare_graph(cur)
+        for _ in range(n):                      # interleave the launches so the lanes advance together
+            for p in self.parts:
+                with torch.cuda.stream(p.stream):
+                    p.graph.launch()
+        for p in self.parts:
+            cur.wait_stream(p.stream)
         return self.x

@@ -48,13 +48,15 @@ def sample_stDiff(model,
                   step_noise=None,
                   seed=None,
                   use_graph=True,
-                  is_tqdm=True):
+                  is_tqdm=True,
+                  lanes=None):
     """Reverse diffusion with the known genes re-spliced after every step (sample.py:22-101).
 
     Returns a host float32 ndarray [N, G].  Keyword-only extras (not in the reference): ``x_T`` / ``step_noise``
     inject the initial draw [N,G] and the per-step draws [n_steps-ish, N, G] (row i is used at timestep
     timesteps[0]-i) for bit-reproducible parity runs; otherwise noise comes from an in-kernel Philox stream keyed
-    by ``seed`` (default torch.initial_seed()), the global row index and the timestep."""
+    by ``seed`` (default torch.initial_seed()), the global row index and the timestep.  ``lanes``: concurrent chunk
+    groups on separate HIP streams (default: engine.default_lanes; results do not depend on it)."""
     if not is_condi:
         raise ValueError("is_condi=False passes y=None to cond_layer (sample.py:13-14): unsupported by the reference "
                          "model as well")
@@ -79,8 +81,8 @@ def sample_stDiff(model,
     if seed is None:
         seed = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
     with torch.no_grad():
-        smp = E.ReverseSampler(eng, noise_scheduler, lens, x_cond, gt_t, mask_t, pred_type=model_pred_type, seed=seed,
-                               use_graph=use_graph)
+        smp = E.LanedSampler(eng, noise_scheduler, lens, x_cond, gt_t, mask_t, pred_type=model_pred_type, seed=seed,
+                             use_graph=use_graph, lanes=1 if step_noise is not None else lanes)
         smp.init(None if x_T is None else torch.as_tensor(x_T, dtype=torch.float32).to(dev).contiguous())
         z = None if step_noise is None else torch.as_tensor(step_noise, dtype=torch.float32).to(dev).contiguous()
         if is_tqdm:

@@ -54,8 +54,9 @@ def sample_stDiff_sharded(model, dataloader, noise_scheduler, mask, gt, num_step
         timesteps = timesteps[:sample_intermediate]
     if hi > lo:
         with torch.no_grad():
-            smp = E.ReverseSampler(eng, noise_scheduler, my_lens, x_cond[lo:hi].contiguous(), gt_t, mask_t,
-                                   pred_type=model_pred_type, row_offset=lo, seed=seed, use_graph=use_graph)
+            smp = E.LanedSampler(eng, noise_scheduler, my_lens, x_cond[lo:hi].contiguous(), gt_t, mask_t,
+                                 pred_type=model_pred_type, row_offset=lo, seed=seed, use_graph=use_graph,
+                                 lanes=1 if step_noise is not None else None)
             smp.init(None if x_T is None else torch.as_tensor(x_T, dtype=torch.float32)[lo:hi].to(dev).contiguous())
             z = None if step_noise is None else torch.as_tensor(step_noise, dtype=torch.float32)[:, lo:hi].to(dev).contiguous()
             smp.run(timesteps, z)

@@ -162,6 +162,18 @@ def test_sampler_world_size_invariance():
             s.init()
             parts.append(s.run(ts).clone())
     assert torch.equal(torch.cat(parts), ref)
+    # concurrent lanes on one device (separate streams + graphs): same bits for 1, 2 and 3 lanes, graph or eager
+    with torch.no_grad():
+        for lanes, graph in ((1, True), (2, True), (3, True), (2, False)):
+            ls = E.LanedSampler(m.engine(), ns, lens, gt, gt, mask, seed=7, lanes=lanes, use_graph=graph)
+            assert len(ls.parts) == lanes
+            ls.init()
+            ls.run(ts[:2])
+            out = ls.run_more(len(ts) - 2)
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref), (lanes, graph)
+        with pytest.raises(ValueError):
+            E.LanedSampler(m.engine(), ns, lens, gt, gt, mask, seed=7, lanes=2).run(ts, z=torch.zeros(T, N, G, device=DEV))
 
 
 def test_errors_and_quirks():
