@@ -354,8 +354,13 @@ __device__ __forceinline__ void epi_quarter256(const Params& p, const float* cl,
             if (gm[ps] < p.M) {
                 const f32x4 pre = v[ps] + bias4;
                 const f32x4 o = epi_math<EPI, CBF>(pre, g[ps], r[ps]);
-                if constexpr (CBF) st4((bf16_t*)p.C + (size_t)gm[ps] * p.ldc + gn, o);
-                else *(f32x4*)((float*)p.C + (size_t)gm[ps] * p.ldc + gn) = o;
+                // streaming stores: C is far larger than L2 and is next read by another kernel
+                if constexpr (CBF) {
+                    u32x2 rr;
+                    rr[0] = pack2bf(o[0], o[1]);
+                    rr[1] = pack2bf(o[2], o[3]);
+                    __builtin_nontemporal_store(rr, (u32x2*)((bf16_t*)p.C + (size_t)gm[ps] * p.ldc + gn));
+                } else __builtin_nontemporal_store(o, (f32x4*)((float*)p.C + (size_t)gm[ps] * p.ldc + gn));
                 if constexpr (HASC2) st4((bf16_t*)p.C2 + (size_t)gm[ps] * p.ldc2 + gn, pre);
             }
         }
@@ -639,7 +644,8 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
     if (bf && a->M > 128 && a->N > 128) {
         const double b256 = (double)cdiv(a->M, 256) * cdiv(a->N, 256), b128 = (double)cdiv(a->M, 128) * cdiv(a->N, 128);
         const double c256 = ceil(b256 / 256.0) * 2.0, c128 = fmax(1.0, b128 / 512.0) / (a->K >= 2048 ? 0.60 : 0.70);
-        tile = c256 <= c128 ? 3 : 1;
+        // with >= 128 tiles the persistent kernel is preferred outright: concurrent lanes fill its partial last round
+        tile = (b256 >= 128.0 || c256 <= c128) ? 3 : 1;
     }
     if (bf && (forced == 1 || forced == 3)) tile = forced;
     const int bm = tile == 1 ? BM : 256, bn = tile == 1 ? BN : 256;
