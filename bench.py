@@ -128,6 +128,29 @@ def cpu_baseline(rows_chunks=8, steps=12):
                       f"{dt:.2f} s/step, extrapolated to 1000 steps"}
 
 
+def train_throughput(dtype, dev, steps=20, warmup=5):
+    """train cells/s = cells through one full iteration (add-noise, forward, masked MSE, backward,
+    clip, AdamW, operand repack) per second, steady state, reference batch of 512 cells at the cfg2 model."""
+    from stdiff_amd import synth as O
+    from stdiff_amd.train_engine import TrainEngine
+    model = build_model(dtype, dev)
+    eng = TrainEngine(model, lr=1e-4, diffusion_step=T, mask=O.kfold_mask(G, 0))
+    st = torch.from_numpy(O.synth_expression(8 * BATCH, G, 1) * 2 - 1).to(dev)
+    for i in range(warmup):
+        eng.step(st[:BATCH], st[:BATCH])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        lo = (i % 8) * BATCH
+        eng.step(st[lo:lo + BATCH], st[lo:lo + BATCH])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    loss = float(eng.loss)
+    assert loss == loss, "non-finite training loss"
+    return {"cells_per_s": round(BATCH / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch": BATCH, "dtype": dtype,
+            "tflops": round(3 * BATCH * (6 * G * H + 512 * H + 222 * H * H + 24 * BATCH * H) / dt / 1e12, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,6 +160,7 @@ def main():
     ap.add_argument("--rows", type=int, default=20000, help="spots per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary metric (train cells/s)")
     ap.add_argument("--lanes", type=int, default=0, help="concurrent chunk groups per GPU (0 = engine default)")
     args = ap.parse_args()
 
@@ -217,6 +241,10 @@ def main():
         with torch.no_grad():
             rec["roofline"] = measure_gemm_roofline(eng, eng.workspace(lens, lane=99), args.dtype)
         rec["roofline"]["whole_step_frac"] = round(rec["step_tflops"] / PEAK[args.dtype], 4)
+        if world == 1 and not args.no_train:
+            del smp
+            torch.cuda.empty_cache()
+            rec["train"] = train_throughput(args.dtype, dev)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
         print(json.dumps(rec), flush=True)

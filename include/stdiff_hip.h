@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define STDIFF_ABI_VERSION 1
+#define STDIFF_ABI_VERSION 2
 
 enum { STDIFF_F32 = 0, STDIFF_BF16 = 1 };
 
@@ -66,6 +66,10 @@ typedef struct {
     const void* gate; int ldgate;
     const float* res; int ldres;
     void* C2; int ldc2;
+    /* optional split-K scratch (fp32, 16-byte aligned, caller-owned; NULL = never split).  Outputs with few tiles and a
+     * long K (the batch-sized GEMMs of a training step) are cut along K into partial products there and summed in a
+     * fixed order by a second kernel that applies the epilogue: deterministic, no atomics. */
+    void* workspace; long long workspace_bytes;
 } stdiff_gemm_args;
 int stdiff_gemm(const stdiff_gemm_args* a, void* stream);
 

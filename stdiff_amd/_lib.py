@@ -23,7 +23,8 @@ class GemmArgs(C.Structure):
                 ("epi", i32),
                 ("gate", vp), ("ldgate", i32),
                 ("res", vp), ("ldres", i32),
-                ("C2", vp), ("ldc2", i32)]
+                ("C2", vp), ("ldc2", i32),
+                ("workspace", vp), ("workspace_bytes", C.c_longlong)]
 
 
 class StepArgs(C.Structure):
@@ -105,7 +106,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.stdiff_abi_version() != 1:
+        if L.stdiff_abi_version() != 2:
             raise RuntimeError("libstdiff_hip.so ABI version mismatch")
         _lib = L
     return _lib

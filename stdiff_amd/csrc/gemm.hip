@@ -50,6 +50,8 @@ struct Params {
     void* C2; int ldc2;
     int vec;  // every epilogue pointer / stride allows aligned 4-wide (16 B fp32, 8 B bf16) access and N % 8 == 0
     int tiles_m, tiles_n;
+    int ksplit, nk_per;  // split-K (128 x 128 kernel): grid = tiles * ksplit, split s covers K-slabs [s*nk_per, ..)
+    float* ws; int ldws; // partial products [ksplit][M][ldws] fp32
 };
 
 __device__ __forceinline__ void tile_of(int bid, int nblk, int tiles_m, int tiles_n, int& tm, int& tn) {
@@ -183,7 +185,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
     int tm, tn;
-    tile_of(blockIdx.x, gridDim.x, p.tiles_m, p.tiles_n, tm, tn);
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int split = blockIdx.x / ntiles;
+    tile_of(blockIdx.x - split * ntiles, ntiles, p.tiles_m, p.tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -262,12 +266,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
         }
     };
 
-    const int nk = p.K / BK;
-    gload(0);
+    const int kb = split * p.nk_per, nk = min(p.K / BK - kb, p.nk_per);     // this block's K-slabs
+    gload(kb * BK);
     sstore(0);
     __syncthreads();
     for (int k = 0; k < nk; ++k) {
-        if (k + 1 < nk) gload((k + 1) * BK);
+        if (k + 1 < nk) gload((kb + k + 1) * BK);
         compute(k & 1);
         if (k + 1 < nk) sstore((k + 1) & 1);
         __syncthreads();
@@ -283,6 +287,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
             *(f32x4*)(cl + m * CLD + n) = acc[mt][nt];
         }
     __syncthreads();
+    if (p.ksplit > 1) {                 // partial product -> workspace slice; splitk_reduce_kernel finishes the job
+        float* w = p.ws + (size_t)split * p.M * p.ldws;
+#pragma unroll 1
+        for (int i = 0; i < 16; ++i) {
+            const int r = (tid >> 5) + 8 * i, c4 = (tid & 31) * 4;
+            const int gm = m0 + r, gn = n0 + c4;
+            if (gm < p.M && gn < p.ldws) *(f32x4*)(w + (size_t)gm * p.ldws + gn) = *(const f32x4*)(cl + r * CLD + c4);
+        }
+        return;
+    }
     if (p.vec) {
 #define STDIFF_CALL128(E) epi_rows128<E, T>(p, cl, tid, m0, n0)
         STDIFF_EPI_DISPATCH(STDIFF_CALL128)
@@ -294,6 +308,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
         const int gm = m0 + r, gn = n0 + c4;
         if (gm < p.M && gn < p.N) epilogue4_slow<T>(p, gm, gn, *(const f32x4*)(cl + r * CLD + c4));
     }
+}
+
+// sum of the split-K partial products in slice order (deterministic) + the full epilogue; one thread = 4 columns
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(Params p) {
+    const int per_row = p.ldws >> 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= p.M * per_row) return;
+    const int gm = idx / per_row, gn = (idx - gm * per_row) * 4;
+    const float* w = p.ws + (size_t)gm * p.ldws + gn;
+    f32x4 v = *(const f32x4*)w;
+    for (int s = 1; s < p.ksplit; ++s) v += *(const f32x4*)(w + (size_t)s * p.M * p.ldws);
+    epilogue4_slow<T>(p, gm, gn, v);
 }
 
 // ================================================================ bf16, 256 x 256 tile, 4 phases per K-slab, counted DMA waits
@@ -374,8 +401,8 @@ __device__ __forceinline__ void epi_quarter256(const Params& p, const float* cl,
 // latency and most of the store drain disappear from the per-tile cost.  The epilogue uses raw barriers + lgkmcnt
 // waits (a __syncthreads would wait for the DMA and the global stores as well).
 #ifdef STDIFF_GEMM_STAMPS
-__device__ unsigned long long g_stamps[256 * 8 * 4];
-#define STDIFF_STAMP(k) do { if (tid == 0 && blockIdx.x < 256 && iter < 8) g_stamps[(blockIdx.x * 8 + iter) * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long g_stamps[256 * 8 * 8];      // [block][tile][0..3 realtime (100 MHz), 4..7 shader clock]
+#define STDIFF_STAMP(k) do { if (tid == 0 && blockIdx.x < 256 && iter < 8) { g_stamps[(blockIdx.x * 8 + iter) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); g_stamps[(blockIdx.x * 8 + iter) * 8 + 4 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define STDIFF_STAMP(k) do {} while (0)
 #endif
@@ -651,7 +678,21 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
     const int bm = tile == 1 ? BM : 256, bn = tile == 1 ? BN : 256;
     p.tiles_m = cdiv(a->M, bm);
     p.tiles_n = cdiv(a->N, bn);
-    dim3 grid(p.tiles_m * p.tiles_n), block(tile == 1 ? NT : 512);
+    p.ksplit = 1; p.nk_per = a->K / bk; p.ws = nullptr; p.ldws = 0;
+    if (tile == 1 && a->workspace && ((uintptr_t)a->workspace & 15) == 0) {
+        // few tiles x long K (batch-sized training GEMMs): one block per tile would walk K alone on a mostly idle chip
+        const long tiles = (long)p.tiles_m * p.tiles_n;
+        const int nk = a->K / bk, ldws = (a->N + 3) & ~3;
+        int S = (int)fmin(fmin(16.0, nk / 4.0), 384.0 / tiles);
+        const long long per = (long long)a->M * ldws * 4;
+        if (S > 1 && per * S > a->workspace_bytes) S = (int)(a->workspace_bytes / per);
+        if (S > 1) {
+            p.nk_per = cdiv(nk, S);
+            p.ksplit = cdiv(nk, p.nk_per);
+            p.ws = (float*)a->workspace; p.ldws = ldws;
+        }
+    }
+    dim3 grid(p.tiles_m * p.tiles_n * p.ksplit), block(tile == 1 ? NT : 512);
     if (tile == 3) grid.x = min((int)grid.x, cu_count());      // persistent: one workgroup per CU walks the tiles
     if (!bf)
         hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
@@ -659,6 +700,11 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
         hipLaunchKernelGGL(gemm_nt_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(gemm256p_kernel, grid, block, 0, (hipStream_t)stream, p);
+    if (p.ksplit > 1) {
+        dim3 rg(cdiv((long)p.M * (p.ldws >> 2), 256));
+        if (bf) hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, rg, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(splitk_reduce_kernel<float>, rg, dim3(256), 0, (hipStream_t)stream, p);
+    }
     STDIFF_LAUNCH_STATUS();
     return STDIFF_OK;
 }

@@ -12,9 +12,10 @@ def round_up(a, b):
     return (a + b - 1) // b * b
 
 
-def gemm(A, W, bias=None, out=None, out_dtype=None, epi=L.EPI_BIAS, gate=None, res=None, out2=None, M=None):
+def gemm(A, W, bias=None, out=None, out_dtype=None, epi=L.EPI_BIAS, gate=None, res=None, out2=None, M=None,
+         workspace=None):
     """out[M,N] = epi(A[M,K] @ W[N,K]^T + bias). A/W: same dtype (fp32 or bf16), K-contiguous rows."""
-    require_gpu(A, W, bias, out, gate, res, out2)
+    require_gpu(A, W, bias, out, gate, res, out2, workspace)
     M = A.shape[0] if M is None else M
     N, K = W.shape[0], W.shape[1]
     if out is None:
@@ -32,6 +33,8 @@ def gemm(A, W, bias=None, out=None, out_dtype=None, epi=L.EPI_BIAS, gate=None, r
         a.res, a.ldres = ptr(res), res.stride(0)
     if out2 is not None:
         a.C2, a.ldc2 = ptr(out2), out2.stride(0)
+    if workspace is not None:          # fp32 scratch for split-K (small outputs with a long K)
+        a.workspace, a.workspace_bytes = ptr(workspace), workspace.numel() * workspace.element_size()
     check(lib().stdiff_gemm(C.byref(a), stream()))
     return out
 

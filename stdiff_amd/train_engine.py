@@ -71,6 +71,9 @@ class TrainCore:
             self.wT[n] = torch.empty((cols, ops.round_up(rows, 64)), device=dev, dtype=self.tdt)
         self.refresh_weights(pack=False)
         self._acts = {}
+        # split-K scratch shared by every GEMM of the step (one stream, so uses never overlap): batch-sized outputs
+        # have 32-200 tiles, too few to fill 256 CUs unless the long K axes are cut too
+        self.ws_splitk = torch.empty(16 << 20, device=dev, dtype=torch.float32)
 
     def refresh_weights(self, pack=True):
         if pack:
@@ -115,6 +118,9 @@ class TrainCore:
         self._acts[C] = a
         return a
 
+    def _gemm(self, *args, **kw):
+        return ops.gemm(*args, workspace=self.ws_splitk, **kw)
+
     def _lin(self, name):
         return self.pw.w[name + ".weight"], self.pw.b(name + ".bias")
 
@@ -122,7 +128,7 @@ class TrainCore:
     def forward(self, a, t):
         """a['xp'], a['yp'] hold the packed inputs; returns eps fp32 [C, G] (a['eps'])."""
         H, D = self.H, self.depth
-        g = ops.gemm
+        g = self._gemm
         ops.timestep_embedding(t, self.pw.freqs, out=a["e0"])
         w, b = self._lin("time_emb.mlp.0")
         g(a["e0"], w, b, out=a["e1"], epi=L.EPI_SILU, out2=a["a1"])
@@ -167,13 +173,13 @@ class TrainCore:
             XT = ops.transpose(X, out=a["tB"][:X.shape[1]], rows_pad=Cp)
         gw = self.g[name + ".weight"]
         m = gw.shape[0] if rows is None else rows
-        ops.gemm(dYT[:m], XT[:gw.shape[1]], None, out=gw)
+        self._gemm(dYT[:m], XT[:gw.shape[1]], None, out=gw)
         ops.colsum(dY[:, :m] if rows is not None else dY, self.g[name + ".bias"])
 
     def _dX(self, name, dY, out, epi=L.EPI_BIAS):
         """out (+)= dY W  via the transposed operand copy W^T [in, out_pad]."""
         wt = self.wT[name + ".weight"]
-        return ops.gemm(dY, wt[:, :dY.shape[1]] if wt.shape[1] != dY.shape[1] else wt, None, out=out, epi=epi)
+        return self._gemm(dY, wt[:, :dY.shape[1]] if wt.shape[1] != dY.shape[1] else wt, None, out=out, epi=epi)
 
     def backward(self, a, after_bucket=None):
         """a['deps'] holds d loss / d eps as the packed operand [C, Gp]; fills self.flat_g (overwrite).
@@ -260,16 +266,27 @@ class TrainEngine(TrainCore):
             self.dist = dist
             self.world = dist.get_world_size(process_group)
         self.buckets = self.bucket_ranges()
+        self._graphs, self._stream = {}, None
 
-    def step(self, x, x_cond, noise=None, timesteps=None):
-        """x, x_cond: fp32 [C, G] on the device.  Returns (loss[1], grad_norm[1]) device tensors (no host sync)."""
+    def step(self, x, x_cond, noise=None, timesteps=None, use_graph=False):
+        """x, x_cond: fp32 [C, G] on the device.  Returns (loss[1], grad_norm[1]) device tensors (no host sync).
+
+        use_graph=True replays the whole iteration (≈340 launches: add-noise .. AdamW .. operand repack) as ONE
+        hipGraph per batch size; inputs are staged into fixed buffers first.  Single process only: with a process
+        group the bucketed all-reduce is issued from the host between backward segments."""
         C = x.shape[0]
         dev = self.device
+        if use_graph and self.world == 1:
+            return self._step_graph(x, x_cond, noise, timesteps)
         a = self.acts(C)
         if noise is None:
             noise = torch.randn(x.shape, device=dev)                                   # stDiff_train.py:62
         if timesteps is None:
             timesteps = torch.randint(1, self.T, (C,), device=dev).long()              # :63  (t = 0 never drawn)
+        self._enqueue(a, x, x_cond, noise, timesteps)
+        return self.loss, self.scal[3:4]
+
+    def _enqueue(self, a, x, x_cond, noise, timesteps):
         ops.add_noise_splice(x, noise, timesteps, self.sa, self.sb, self.mask, xp=a["xp"])   # :65-70
         ops.pack_rows(x_cond, self.Gp, self.tdt, out=a["yp"])
         eps = self.forward(a, timesteps)                                               # :72
@@ -289,6 +306,43 @@ class TrainEngine(TrainCore):
                        max_norm=self.max_norm, grad_scale=1.0 / self.world, betas=self.betas, eps=self.eps,
                        weight_decay=self.wd)                                           # :78-80
         self.refresh_weights()
+
+    def _step_graph(self, x, x_cond, noise, timesteps):
+        C, dev = x.shape[0], self.device
+        st = self._graphs.get(C)
+        if st is None:
+            if len(self._graphs) > 3:
+                self._graphs.clear()           # ops.Graph frees its exec handle when collected
+            st = self._graphs[C] = dict(
+                x=torch.empty((C, self.G), device=dev), y=torch.empty((C, self.G), device=dev),
+                noise=torch.empty((C, self.G), device=dev), t=torch.empty((C,), device=dev, dtype=torch.int64),
+                graph=None)
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=dev)       # the legacy default stream cannot be captured
+        cur = torch.cuda.current_stream()
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            st["x"].copy_(x)
+            st["y"].copy_(x_cond)
+            if noise is None:
+                st["noise"].normal_()                                                  # stDiff_train.py:62
+            else:
+                st["noise"].copy_(noise)
+            if timesteps is None:
+                st["t"].random_(1, self.T)                                             # :63  (t = 0 never drawn)
+            else:
+                st["t"].copy_(timesteps)
+            if st["graph"] is None:
+                a = self.acts(C)
+                g = ops.Graph()
+                g.begin()
+                try:
+                    self._enqueue(a, st["x"], st["y"], st["noise"], st["t"])
+                finally:
+                    g.end()
+                st["graph"] = g
+            st["graph"].launch()
+        cur.wait_stream(self._stream)
         return self.loss, self.scal[3:4]
 
 

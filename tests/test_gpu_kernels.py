@@ -95,6 +95,86 @@ def test_gemm_epilogues(ops, L, dt):
     assert relerr(o1, F.gelu(v)) < t2 and relerr(o2, v) < t2
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(512, 1024, 4096), (200, 136, 1024), (64, 1000, 2048), (300, 33, 512)])
+def test_gemm_split_k(ops, L, dt, M, N, K):
+    """Few tiles x long K with a caller workspace: deterministic split-K + reduce kernel, every epilogue kind."""
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1)
+    v = q(A, dt) @ q(W, dt).T + b
+    Ad, Wd, bd = to_dt(A, dt), to_dt(W, dt), b.to(DEV)
+    ws = torch.empty(8 << 20, device=DEV, dtype=torch.float32)
+    tol = 3e-6 if dt == "fp32" else 3e-5
+    out = ops.gemm(Ad, Wd, bd, out_dtype=torch.float32, workspace=ws)
+    assert relerr(out, v) < tol
+    assert torch.equal(out, ops.gemm(Ad, Wd, bd, out_dtype=torch.float32, workspace=ws))          # run-to-run identical
+    assert relerr(out, ops.gemm(Ad, Wd, bd, out_dtype=torch.float32)) < tol                       # vs the unsplit kernel
+    assert relerr(ops.gemm(Ad, Wd, bd, out_dtype=torch.float32, epi=L.EPI_GELU, workspace=ws), F.gelu(v)) < tol
+    res, gate = rnd(M, N, seed=7), rnd(M, N, seed=8)
+    h = res.to(DEV).clone()
+    ops.gemm(Ad, Wd, bd, out=h, epi=L.EPI_GATE_RES, gate=to_dt(gate, dt), res=h, workspace=ws)
+    assert relerr(h, res + q(gate, dt) * v) < tol
+    acc = res.to(DEV).clone()
+    ops.gemm(Ad, Wd, None, out=acc, epi=L.EPI_ACCUM, workspace=ws)
+    assert relerr(acc, res + v - b) < tol
+    o1 = torch.empty(M, N, device=DEV, dtype=Ad.dtype)
+    o2 = torch.empty(M, N, device=DEV, dtype=Ad.dtype)
+    ops.gemm(Ad, Wd, bd, out=o1, epi=L.EPI_GELU_SAVE, out2=o2, workspace=ws)
+    t2 = 5e-3 if dt == "bf16" else tol
+    assert relerr(o1, F.gelu(v)) < t2 and relerr(o2, v) < t2
+    small = torch.empty(16, device=DEV, dtype=torch.float32)                                      # too small: falls back
+    assert relerr(ops.gemm(Ad, Wd, bd, out_dtype=torch.float32, workspace=small), v) < tol
+
+
+@pytest.mark.parametrize("M,N,K", [(600, 520, 256), (257, 264, 64), (1024, 512, 1024)])
+def test_gemm_256_kernel_all_epilogues(ops, L, M, N, K, monkeypatch):
+    """The persistent 256 x 256 bf16 kernel forced (STDIFF_GEMM_TILE=3 is read per call): ragged M / N edges, every
+    epilogue kind, fp32 and bf16 outputs, several tiles per workgroup when tiles > CUs."""
+    monkeypatch.setenv("STDIFF_GEMM_TILE", "3")
+    dt = "bf16"
+    A, W, b = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=K ** -0.5), rnd(N, seed=13, scale=0.1)
+    v = q(A, dt) @ q(W, dt).T + b
+    Ad, Wd, bd = to_dt(A, dt), to_dt(W, dt), b.to(DEV)
+    tol = 3e-5
+    assert relerr(ops.gemm(Ad, Wd, bd, out_dtype=torch.float32), v) < tol
+    assert relerr(ops.gemm(Ad, Wd, None, out_dtype=torch.float32), v - b) < tol
+    assert relerr(ops.gemm(Ad, Wd, bd), v) < 5e-3
+    assert relerr(ops.gemm(Ad, Wd, bd, out_dtype=torch.float32, epi=L.EPI_SILU), F.silu(v)) < tol
+    assert relerr(ops.gemm(Ad, Wd, bd, out_dtype=torch.float32, epi=L.EPI_GELU), F.gelu(v)) < tol
+    g16 = ops.gemm(Ad, Wd, bd, epi=L.EPI_GELU)                      # bf16 output: the polynomial GELU
+    assert relerr(g16, F.gelu(v)) < 5e-3
+    res, gate = rnd(M, N, seed=7), rnd(M, 3 * N, seed=8)
+    gd = to_dt(gate, dt)
+    h = res.to(DEV).clone()
+    ops.gemm(Ad, Wd, bd, out=h, epi=L.EPI_GATE_RES, gate=gd[:, N:2 * N], res=h)
+    assert relerr(h, res + q(gate, dt)[:, N:2 * N] * v) < tol
+    assert relerr(ops.gemm(Ad, Wd, bd, out_dtype=torch.float32, epi=L.EPI_ADD, res=res.to(DEV)), v + res) < tol
+    acc = res.to(DEV).clone()
+    ops.gemm(Ad, Wd, bd, out=acc, epi=L.EPI_ACCUM)
+    assert relerr(acc, res + v) < tol
+    o1 = torch.empty(M, N, device=DEV, dtype=Ad.dtype)
+    o2 = torch.empty(M, N, device=DEV, dtype=Ad.dtype)
+    ops.gemm(Ad, Wd, bd, out=o1, epi=L.EPI_GELU_SAVE, out2=o2)
+    assert relerr(o1, F.gelu(v)) < 5e-3 and relerr(o2, v) < 5e-3
+
+
+def test_gelu_polynomial_accuracy(ops, L, monkeypatch):
+    """gelu_poly4 (bf16 outputs of the 256 x 256 kernel) against erf GELU over the whole input range: the result,
+    read back as bf16, is within one bf16 ulp of the correctly rounded value."""
+    monkeypatch.setenv("STDIFF_GEMM_TILE", "3")
+    M, K = 512, 64
+    A = torch.zeros(M, K)
+    W = torch.zeros(256, K)
+    x_cols = torch.linspace(-9, 9, 256).to(torch.bfloat16).float()
+    A[:, 0] = 1.0
+    W[:, 0] = x_cols
+    out = ops.gemm(to_dt(A, "bf16"), to_dt(W, "bf16"), None, epi=L.EPI_GELU)       # every row = gelu(x_cols)
+    ref = F.gelu(x_cols.double()).float()
+    got = out[0].float().cpu()
+    ulp = torch.maximum(ref.abs(), torch.tensor(1e-30)) * 2.0 ** -8
+    assert bool(((got - ref).abs() <= ulp + 2e-6).all())
+    assert torch.equal(out[0], out[-1])
+
+
 def test_gemm_rejects_bad_shapes(ops):
     A, W = torch.zeros(8, 40, device=DEV), torch.zeros(8, 40, device=DEV)
     with pytest.raises(ValueError):

@@ -131,7 +131,9 @@ def test_clip_adamw_matches_torch():
 
 
 # ---------------------------------------------------------------- whole train step vs the reference goldens
-def test_train_steps_golden_fp32(golden_dir):
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_train_steps_golden_fp32(golden_dir, use_graph):
+    """3 consecutive reference iterations (G6); use_graph=True replays each as one captured hipGraph."""
     from stdiff_amd.train_engine import TrainEngine
     g = np.load(os.path.join(golden_dir, "g6_train.npz"))
     C, G, H, depth, heads, seed, T = [int(v) for v in g["cfg"]]
@@ -142,7 +144,7 @@ def test_train_steps_golden_fp32(golden_dir):
     for i in range(3):
         loss, gn = te.step(x[i * C:(i + 1) * C].contiguous(), xc[i * C:(i + 1) * C].contiguous(),
                            noise=torch.from_numpy(g["noise"][i]).to(DEV),
-                           timesteps=torch.from_numpy(g["timesteps"][i]).to(DEV))
+                           timesteps=torch.from_numpy(g["timesteps"][i]).to(DEV), use_graph=use_graph)
         assert abs(float(loss) - g["loss"][i]) < 1e-5 * max(1.0, g["loss"][i]), i
         assert abs(float(gn) - g["gnorm"][i]) < 1e-4 * g["gnorm"][i], i
         l2 = np.array([float(te.g[n].norm()) for n in names])
