@@ -159,7 +159,7 @@ __device__ __forceinline__ void store_rows(T* dst, const f32x16 (&o)[D / 32], fl
 
 // ================================================================ forward
 template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv, int ldqkv, T* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ qkv, int ldqkv, T* __restrict__ out,
                                                        int ldo, float* __restrict__ lse,
                                                        const int32_t* __restrict__ cu_rows, int heads, float c_log2) {
     using C = ACfg<T, D>;
@@ -201,37 +201,50 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const T* __restrict__ qkv
         if constexpr (BF) {
             if (j + 1 < ntiles) { sk.gload(kbase, ldqkv, r0, k0 + BKV, len, tid); sv.gload(vbase, ldqkv, r0, k0 + BKV, len, tid); }
         }
+        // 64 keys per softmax step (two 32-key MFMA tiles).  The running maximum is raised LAZILY: only when some
+        // lane's new maximum exceeds its reference by more than 2^LAZY does the wave rescale O and l (a skipped
+        // rescale multiplies by exactly 1, so nothing changes but the work: the accumulators stay in place instead of
+        // a read-modify-write of all of them per tile).  exp2 is the bare v_exp_f32.
+        constexpr float LAZY = 6.0f;
+        const bool two = k0 + 32 < len;
+        f32x16 sa = rows_dot_regs<T, D>(kls, 0, qf, lane);           // S^T[key, q], raw scores
+        f32x16 sb;
+        if (two) sb = rows_dot_regs<T, D>(kls, 1, qf, lane);
+        else {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            if (k0 + kt * 32 >= len) break;
-            f32x16 s = rows_dot_regs<T, D>(kls, kt, qf, lane);       // S^T[key, q]
-            // online softmax in base 2; keys past the chunk get -inf
-            const bool tail = k0 + kt * 32 + 32 > len;
-            float mt = -INFINITY;
+            for (int r = 0; r < 16; ++r) sb[r] = -INFINITY;
+        }
+        if (k0 + 64 > len) {                                         // keys past the chunk get -inf
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = s[r] * c_log2;
-                if (tail && k0 + kt * 32 + kappa(r, hh) >= len) v = -INFINITY;
-                s[r] = v;
-                mt = fmaxf(mt, v);
+                if (k0 + kappa(r, hh) >= len) sa[r] = -INFINITY;
+                if (k0 + 32 + kappa(r, hh) >= len) sb[r] = -INFINITY;
             }
-            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        }
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, fmaxf(sa[r], sb[r]));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * c_log2;
+        if (__builtin_amdgcn_ballot_w64(mt > m_run + LAZY) != 0) {
             const float m_new = fmaxf(m_run, mt);
-            const float alpha = exp2f(m_run - m_new);
-            float ps = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[r] = exp2f(s[r] - m_new);
-                ps += s[r];
-            }
-            l_run = l_run * alpha + ps;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
             m_run = m_new;
 #pragma unroll
             for (int b = 0; b < D / 32; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[b][r] *= alpha;
-            tr_accumulate<T, D>(o, vls, kt, s, lane);                // O^T[d, q] += V^T . P^T
         }
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sa[r] = __builtin_amdgcn_exp2f(fmaf(sa[r], c_log2, -m_run));
+            sb[r] = __builtin_amdgcn_exp2f(fmaf(sb[r], c_log2, -m_run));
+            ps += sa[r] + sb[r];
+        }
+        l_run += ps;
+        tr_accumulate<T, D>(o, vls, 0, sa, lane);                    // O^T[d, q] += V^T . P^T
+        if (two) tr_accumulate<T, D>(o, vls, 1, sb, lane);
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (qrow < len) {
