@@ -114,6 +114,12 @@ int stdiff_timestep_embedding(const int64_t* t, const float* freqs, void* out, i
 /* dst[R, ldd] (dtype) = src[R, C] fp32, columns C..Cpad-1 zero-filled (operand packing for the MFMA kernels). */
 int stdiff_pack_rows(const float* src, int lds, void* dst, int ldd, int dtype, int R, int C, int Cpad, void* stream);
 
+/* Shuffled mini-batch from device-resident data (the DataLoader of process/data.py:64-75 with shuffle=True, minus the
+ * host: TensorDataset.__getitem__ + default collate = a row gather): da[r,:] = a[idx[r],:] and, when b != NULL,
+ * db[r,:] = b[idx[r],:] for r < R.  fp32, idx int64 on the device. */
+int stdiff_gather_rows2(const float* a, int lda, const float* b, int ldb, const int64_t* idx, float* da, int ldda,
+                        float* db, int lddb, int R, int C, void* stream);
+
 /* ---------------------------------------------------------------- diffusion arithmetic
  * One reverse step + known-gene splice, fused (NoiseScheduler.step, stDiff_scheduler.py:103-139 ->
  * reconstruct_x0 :68-78, q_posterior :80-90, get_variance :92-100; splice model/sample.py:94-95):

@@ -113,6 +113,33 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict_
     }
 }
 
+// dst[r, :] = src[idx[r], :] for two row-aligned matrices at once (the (x, x_cond) pair of a shuffled mini-batch):
+// one wave per output row, 16-byte pieces when both rows allow it.  idx outside [0, n_src) is the caller's bug: the
+// host wrapper checks the permutation it builds.
+__global__ __launch_bounds__(256) void gather_rows2_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b,
+                                                           int ldb, const int64_t* __restrict__ idx, float* da, int ldda,
+                                                           float* db, int lddb, int R, int C, int vec) {
+    const int lane = threadIdx.x & 63;
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += gridDim.x * 4) {
+        const size_t s = (size_t)idx[r];
+        const float* sa = a + s * lda;
+        const float* sb = b ? b + s * ldb : nullptr;
+        float* oa = da + (size_t)r * ldda;
+        float* ob = db + (size_t)r * lddb;
+        if (vec) {
+            for (int c = lane * 4; c < C; c += 256) {
+                *(f32x4*)(oa + c) = *(const f32x4*)(sa + c);
+                if (sb) *(f32x4*)(ob + c) = *(const f32x4*)(sb + c);
+            }
+        } else {
+            for (int c = lane; c < C; c += 64) {
+                oa[c] = sa[c];
+                if (sb) ob[c] = sb[c];
+            }
+        }
+    }
+}
+
 inline int ew_grid(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 8); }
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -175,6 +202,19 @@ extern "C" int stdiff_pack_rows(const float* src, int lds, void* dst, int ldd, i
         hipLaunchKernelGGL(pack_rows_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, src, lds, (bf16_t*)dst, ldd, R, C, Cpad);
     else
         hipLaunchKernelGGL(pack_rows_kernel<float>, grid, block, 0, (hipStream_t)stream, src, lds, (float*)dst, ldd, R, C, Cpad);
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}
+
+extern "C" int stdiff_gather_rows2(const float* a, int lda, const float* b, int ldb, const int64_t* idx, float* da,
+                                   int ldda, float* db, int lddb, int R, int C, void* stream) {
+    STDIFF_CHECK_ARG(a && idx && da && R >= 0 && C > 0 && lda >= C && ldda >= C);
+    STDIFF_CHECK_ARG(!b || (db && ldb >= C && lddb >= C));
+    if (R == 0) return STDIFF_OK;
+    int vec = C % 4 == 0 && lda % 4 == 0 && ldda % 4 == 0 && al16(a) && al16(da);
+    if (b) vec = vec && ldb % 4 == 0 && lddb % 4 == 0 && al16(b) && al16(db);
+    hipLaunchKernelGGL(gather_rows2_kernel, dim3(std::min(cdiv(R, 4), 4096)), dim3(256), 0, (hipStream_t)stream, a, lda, b,
+                       ldb, idx, da, ldda, db, lddb, R, C, vec);
     STDIFF_LAUNCH_STATUS();
     return STDIFF_OK;
 }

@@ -12,6 +12,10 @@ from .. import engine as E
 def _collect_condition(dataloader, device):
     """One pass over the DataLoader: the condition rows and the chunk (mini-batch) lengths, in loader order.
     The reference re-reads and re-uploads the same batches every step (sample.py:9-10); they never change."""
+    from ..process.data import DeviceLoader
+    if isinstance(dataloader, DeviceLoader) and not dataloader.is_shuffle and dataloader.world == 1 \
+            and dataloader.x_cond.device == torch.empty(0, device=device).device:
+        return dataloader.x_cond, list(dataloader.lens)            # already resident, already in chunk order
     conds, lens = [], []
     for _, x_cond in dataloader:
         conds.append(x_cond.float().to(device))

@@ -103,6 +103,21 @@ def pack_rows(src, cpad, dtype, out=None):
     return out
 
 
+def gather_rows2(a, b, idx, out_a=None, out_b=None):
+    """(a[idx], b[idx]) for fp32 [N, C] matrices on the device and an int64 device index vector (b may be None)."""
+    require_gpu(a, b, idx, out_a, out_b)
+    R, Cc = idx.shape[0], a.shape[1]
+    assert idx.dtype == torch.int64 and a.dtype == torch.float32 and (b is None or (b.dtype == a.dtype and b.shape == a.shape))
+    if out_a is None:
+        out_a = torch.empty((R, Cc), device=a.device, dtype=torch.float32)
+    if b is not None and out_b is None:
+        out_b = torch.empty((R, Cc), device=a.device, dtype=torch.float32)
+    check(lib().stdiff_gather_rows2(ptr(a), a.stride(0), ptr(b), b.stride(0) if b is not None else 0, ptr(idx),
+                                    ptr(out_a), out_a.stride(0), ptr(out_b), out_b.stride(0) if b is not None else 0,
+                                    R, Cc, stream()))
+    return out_a, out_b
+
+
 def ddpm_step(x, eps, gt, mask, coef, t_dev, t_first, z_base=None, seed=0, row_offset=0, xp=None, pred_type=0):
     require_gpu(x, eps, gt, mask, coef, t_dev, z_base, xp)
     a = L.StepArgs()

@@ -127,6 +127,15 @@ def test_data_loader_chunking():
     assert not torch.equal(a, torch.from_numpy(x).float()) and torch.equal(a.sort(0).values, torch.from_numpy(x).float())
 
 
+def test_device_loader_needs_gpu():
+    from stdiff_amd.process.data import get_data_loader
+    x = np.zeros((8, 4), dtype=np.float32)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        get_data_loader(x, x, batch_size=4, device="cpu")
+    with pytest.raises(ValueError):
+        get_data_loader(x, x, batch_size=4, world=2)
+
+
 def test_sharding_plan():
     from stdiff_amd.parallel import shard_chunks
     lens = [512] * 39 + [32]                       # BASELINE configs[1]: 20000 rows in chunks of 512

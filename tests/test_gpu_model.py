@@ -176,6 +176,40 @@ def test_sampler_world_size_invariance():
             E.LanedSampler(m.engine(), ns, lens, gt, gt, mask, seed=7, lanes=2).run(ts, z=torch.zeros(T, N, G, device=DEV))
 
 
+def test_device_loader_matches_host_loader():
+    """the device-resident loader yields the batches of the reference DataLoader (same seed -> same
+    permutation, same partial last batch), epoch after epoch; rank/world shards whole batches; an unshuffled loader
+    hands sample_stDiff its resident condition matrix without a copy."""
+    from stdiff_amd import ops
+    from stdiff_amd.process.data import get_data_loader, DeviceLoader
+    from stdiff_amd.model.sample import _collect_condition
+    N, G, B = 203, 40, 32
+    x = np.arange(N * G, dtype=np.float32).reshape(N, G)
+    xc = -x
+    idx = torch.randperm(N, generator=torch.Generator().manual_seed(1)).to(DEV)
+    ga, gb = ops.gather_rows2(torch.from_numpy(x).to(DEV), torch.from_numpy(xc).to(DEV), idx)
+    assert torch.equal(ga.cpu(), torch.from_numpy(x)[idx.cpu()]) and torch.equal(gb, -ga)
+    odd = torch.from_numpy(x).to(DEV)[:, :33]                       # unaligned rows: scalar path
+    assert torch.equal(ops.gather_rows2(odd, None, idx)[0], odd[idx])
+    for shuffle in (False, True):
+        torch.manual_seed(77)
+        host = get_data_loader(x, xc, batch_size=B, is_shuffle=shuffle)
+        torch.manual_seed(77)
+        dev = get_data_loader(x, xc, batch_size=B, is_shuffle=shuffle, device=DEV)
+        assert isinstance(dev, DeviceLoader) and len(dev) == len(host) == 7
+        for epoch in range(3):
+            hb, db = list(host), list(dev)
+            assert [b[0].shape[0] for b in db] == [32] * 6 + [11]
+            for (h0, h1), (d0, d1) in zip(hb, db):
+                assert d0.device.type == "cuda" and torch.equal(d0.cpu(), h0) and torch.equal(d1.cpu(), h1)
+    plain = get_data_loader(x, xc, batch_size=B, is_shuffle=False, device=DEV)
+    cond, lens = _collect_condition(plain, torch.device(DEV))
+    assert cond.data_ptr() == plain.x_cond.data_ptr() and lens == [32] * 6 + [11]
+    shards = [get_data_loader(x, xc, batch_size=B, is_shuffle=False, device=DEV, rank=r, world=2) for r in range(2)]
+    assert [len(s_) for s_ in shards] == [3, 3]                     # 7 batches: the incomplete round is dropped
+    assert torch.equal(next(iter(shards[1]))[0].cpu(), torch.from_numpy(x[32:64]))
+
+
 def test_errors_and_quirks():
     from stdiff_amd.model.stDiff_model import DiT_stDiff
     from stdiff_amd.model.sample import sample_stDiff
