@@ -1,0 +1,101 @@
+"""5-fold gene cross-validation driver of the reference (`diffusion_impute`, test-stDiff.py:62-187) over the MI355X
+hot path: arrays in, arrays out (the reference reads .h5ad through scanpy; preprocessing stays outside).
+
+Per fold (test-stDiff.py:73-185): KFold(n_splits, shuffle=True, random_state=rand) over the genes -> mask (test genes
+0); `[0,1] -> [-1,1]` mapping of the scRNA matrix, its masked copy, and the masked spatial matrix; a fresh
+DiT_stDiff under torch.manual_seed(1202); normal_train_stDiff on shuffled (seq, seq*mask) batches unless a
+checkpoint `stDiff%d.pt` exists (then load_state_dict, :151); sample_stDiff over unshuffled spatial batches with
+gt = masked spatial; the fold's TEST genes are scattered into the result (:181), which is mapped back to [0,1]
+(:184).  Folds are independent: `folds=` selects a subset so that ranks / GPUs can split them."""
+import os
+
+import numpy as np
+import torch
+
+from .model.sample import sample_stDiff
+from .model.stDiff_model import DiT_stDiff
+from .model.stDiff_scheduler import NoiseScheduler
+from .model.stDiff_train import normal_train_stDiff
+from .process.data import get_data_loader
+
+
+def kfold_gene_splits(gene_num, n_splits=5, rand=0):
+    """[(train_ind, test_ind)] of sklearn's KFold(n_splits, shuffle=True, random_state=rand).split(range(gene_num))
+    (test-stDiff.py:73-79): RandomState(rand) shuffles arange(n) once; fold k's test set is the k-th consecutive slice
+    (the first n % n_splits folds one longer), SORTED as sklearn returns it; train = the rest, ascending."""
+    idx = np.arange(gene_num)
+    np.random.RandomState(rand).shuffle(idx)
+    sizes = np.full(n_splits, gene_num // n_splits, dtype=int)
+    sizes[: gene_num % n_splits] += 1
+    out, start = [], 0
+    for k in range(n_splits):
+        test_mask = np.zeros(gene_num, dtype=bool)
+        test_mask[idx[start:start + sizes[k]]] = True
+        out.append((np.flatnonzero(~test_mask), np.flatnonzero(test_mask)))
+        start += sizes[k]
+    return out
+
+
+def fold_mask(gene_num, test_ind):
+    mask = np.ones((gene_num,), dtype='float32')                     # test-stDiff.py:92-96
+    mask[test_ind] = 0
+    return mask
+
+
+def diffusion_impute(data_seq_array, data_spatial_array, *, lr=0.00016046744893538737, depth=6, num_epoch=900,
+                     diffusion_step=1500, batch_size=512, hidden_size=1024, head=16, n_splits=5, rand=0,
+                     device=torch.device('cuda:0'), save_dir=None, folds=None, compute_dtype=None, is_tqdm=False,
+                     device_loader=True, sample_seed=None):
+    """Returns (impu [cells, genes] in [0,1], with every gene imputed by the fold that held it out; columns of folds not
+    in `folds` stay 0), like the reference's `impu`.  Defaults are the reference's (test-stDiff.py:27-34,64-70).
+
+    save_dir: directory of `stDiff%d.pt` checkpoints (1-based fold index, :88); existing files are loaded instead of
+    training, new ones are written after training (the reference has the save commented out; loading is what makes
+    its checkpoints usable here: same state-dict keys)."""
+    seq0 = np.ascontiguousarray(data_seq_array, dtype=np.float32)
+    st0 = np.ascontiguousarray(data_spatial_array, dtype=np.float32)
+    cell_num, gene_num = st0.shape
+    if seq0.shape[1] != gene_num:
+        raise ValueError("scRNA and spatial matrices must share their gene axis")
+    splits = kfold_gene_splits(gene_num, n_splits, rand)
+    torch.manual_seed(10)                                            # :75
+    all_pred_res = np.zeros_like(st0)
+    loader_kw = {"device": device} if device_loader else {}
+    for k, (train_ind, test_ind) in enumerate(splits):
+        idx = k + 1
+        if folds is not None and k not in folds:
+            continue
+        mask = fold_mask(gene_num, test_ind)
+        seq = seq0 * 2 - 1                                           # :103-110
+        data_seq_masked = (seq0 * mask) * 2 - 1
+        data_spatial_masked = (st0 * mask) * 2 - 1
+        dataloader = get_data_loader(seq, data_seq_masked, batch_size=batch_size, is_shuffle=True, **loader_kw)
+        seed = 1202                                                  # :118-121
+        torch.manual_seed(seed)
+        torch.cuda.manual_seed_all(seed)
+        kw = {} if compute_dtype is None else {"compute_dtype": compute_dtype}
+        model = DiT_stDiff(input_size=gene_num, hidden_size=hidden_size, depth=depth, num_heads=head, classes=6,
+                           mlp_ratio=4.0, dit_type='dit', **kw)
+        model.to(device)
+        model.train()
+        ckpt = None if save_dir is None else os.path.join(save_dir, 'stDiff%d.pt' % idx)
+        if ckpt is not None and os.path.isfile(ckpt):
+            model.load_state_dict(torch.load(ckpt, map_location=device, weights_only=True))      # :151
+        else:
+            normal_train_stDiff(model, dataloader=dataloader, lr=lr, num_epoch=num_epoch,
+                                diffusion_step=diffusion_step, device=device, pred_type='noise', mask=mask,
+                                is_tqdm=is_tqdm)
+            if ckpt is not None:
+                os.makedirs(save_dir, exist_ok=True)
+                torch.save(model.state_dict(), ckpt)
+        noise_scheduler = NoiseScheduler(num_timesteps=diffusion_step, beta_schedule='cosine')
+        dataloader = get_data_loader(data_spatial_masked, data_spatial_masked, batch_size=batch_size, is_shuffle=False,
+                                     **loader_kw)
+        model.eval()
+        imputation = sample_stDiff(model, device=device, dataloader=dataloader, noise_scheduler=noise_scheduler,
+                                   mask=mask, gt=data_spatial_masked, num_step=diffusion_step,
+                                   sample_shape=(cell_num, gene_num), is_condi=True,
+                                   sample_intermediate=diffusion_step, model_pred_type='noise',
+                                   is_classifier_guidance=False, omega=0.2, is_tqdm=is_tqdm, seed=sample_seed)
+        all_pred_res[:, test_ind] = imputation[:, test_ind]          # :181
+    return (all_pred_res + 1) / 2                                    # :184

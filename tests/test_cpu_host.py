@@ -136,6 +136,20 @@ def test_device_loader_needs_gpu():
         get_data_loader(x, x, batch_size=4, world=2)
 
 
+def test_cv_gene_splits_match_sklearn():
+    """the driver's fold construction is sklearn's KFold(shuffle=True, random_state) (test-stDiff.py:73)."""
+    from sklearn.model_selection import KFold
+    from stdiff_amd.driver import kfold_gene_splits, fold_mask
+    from stdiff_amd.synth import kfold_mask
+    for n, k, rs in ((1000, 5, 0), (33, 5, 0), (158, 5, 3), (40, 4, 7)):
+        ref = list(KFold(n_splits=k, shuffle=True, random_state=rs).split(np.arange(n)))
+        got = kfold_gene_splits(n, k, rs)
+        assert len(ref) == len(got)
+        for (tr, te), (gtr, gte) in zip(ref, got):
+            assert np.array_equal(tr, gtr) and np.array_equal(te, gte)
+        assert np.array_equal(fold_mask(n, got[0][1]), kfold_mask(n, 0, k, rs))
+
+
 def test_sharding_plan():
     from stdiff_amd.parallel import shard_chunks
     lens = [512] * 39 + [32]                       # BASELINE configs[1]: 20000 rows in chunks of 512
