@@ -191,6 +191,19 @@ typedef struct {
 } stdiff_adamw_args;
 int stdiff_clip_adamw(const stdiff_adamw_args* a, void* stream);
 
+/* ---------------------------------------------------------------- per-gene accuracy statistics (test-stDiff.py:203-364)
+ * One pass over imputed x and measured y ([N, G] fp32): partials[chunk][k][g], k = sum x, sum y, sum xy, sum xx,
+ * sum yy, max x, max y in float64 for the rows of slab `chunk` (rows cut into `chunks` equal slabs; the caller adds
+ * the slabs in order: deterministic).  Pearson (np.corrcoef / scipy pearsonr), cosine, RMSE after zscore
+ * (CalculateMeteics.RMSE :345-364) and SSIM after scale_max (cal_ssim :203-221, SSIM :271-298) are closed forms of
+ * these.  partials: device float64 [chunks, 7, G]. */
+int stdiff_column_moments(const float* x, int ldx, const float* y, int ldy, double* partials, int chunks, int N, int G,
+                          void* stream);
+/* Jensen-Shannon divergence of the sum-normalised columns (CalculateMeteics.JS :318-343 with scale_plus :237-242 and
+ * scipy.stats.entropy): partials[chunk][g] in float64; inv_sum_* = 1 / column sums (device float64 [G]). */
+int stdiff_column_js(const float* x, int ldx, const float* y, int ldy, const double* inv_sum_x, const double* inv_sum_y,
+                     double* partials, int chunks, int N, int G, void* stream);
+
 /* ---------------------------------------------------------------- whole-denoiser forward (inference)
  * DiT_stDiff.forward after the conditioning (stDiff_model.py:240-243): in_layer, depth x DiTblock, FinalLayer,
  * on R rows split into chunks (attention is per chunk).  Inputs: xp = packed x [R,Gp], s = silu(c) [R,H].

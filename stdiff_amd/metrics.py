@@ -1,0 +1,96 @@
+"""Per-gene accuracy metrics of the reference's evaluation block (test-stDiff.py:203-364) from two HBM passes over
+the imputed and measured matrices (csrc/metrics.hip); the closed forms below run on [G]-sized float64 vectors.
+
+Covered: PCC (per-gene Pearson), cosine (north_star), RMSE after zscore, SSIM after scale_max, JS after scale_plus.
+Not covered: SPCC (Spearman needs a per-gene sort of N values; the reference's rank statistics stay on the host) and
+the scanpy clustering scores."""
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import check, lib, ptr, require_gpu, stream
+
+
+def _chunks(n):
+    return int(min(64, max(1, (n + 255) // 256)))
+
+
+def column_moments(x, y):
+    """x, y: fp32 [N, G] device tensors -> dict of float64 numpy [G]: n, sx, sy, sxy, sxx, syy, maxx, maxy."""
+    require_gpu(x, y)
+    if x.shape != y.shape or x.dim() != 2 or x.dtype != torch.float32 or y.dtype != torch.float32:
+        raise ValueError("x and y must be fp32 [N, G] of equal shape")
+    if x.stride(1) != 1 or y.stride(1) != 1:
+        raise ValueError("rows must be contiguous")
+    N, G = x.shape
+    ch = _chunks(N)
+    part = torch.empty((ch, 7, G), device=x.device, dtype=torch.float64)
+    check(lib().stdiff_column_moments(ptr(x), x.stride(0), ptr(y), y.stride(0), ptr(part), ch, N, G, stream()))
+    p = part.cpu().numpy()
+    m = {"n": float(N)}
+    for k, name in enumerate(("sx", "sy", "sxy", "sxx", "syy")):
+        acc = np.zeros(G)
+        for c in range(ch):                    # slab order: deterministic
+            acc += p[c, k]
+        m[name] = acc
+    m["maxx"], m["maxy"] = p[:, 5].max(axis=0), p[:, 6].max(axis=0)
+    return m
+
+
+def _pearson(m):
+    n = m["n"]
+    cov = m["sxy"] - m["sx"] * m["sy"] / n
+    vx = m["sxx"] - m["sx"] ** 2 / n
+    vy = m["syy"] - m["sy"] ** 2 / n
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return cov / np.sqrt(vx * vy)
+
+
+def _ssim_scale_max(m):
+    """cal_ssim (:203-221) of the columns after scale_max (:224-229): both maxima become 1, so M = 1."""
+    n = m["n"]
+    ax, ay = 1.0 / m["maxx"], 1.0 / m["maxy"]
+    mu1, mu2 = m["sx"] / n * ax, m["sy"] / n * ay
+    var1 = (m["sxx"] / n) * ax * ax - mu1 ** 2
+    var2 = (m["syy"] / n) * ay * ay - mu2 ** 2
+    s1, s2 = np.sqrt(np.maximum(var1, 0)), np.sqrt(np.maximum(var2, 0))
+    s12 = (m["sxy"] / n) * ax * ay - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    C3 = C2 / 2
+    l12 = (2 * mu1 * mu2 + C1) / (mu1 ** 2 + mu2 ** 2 + C1)
+    c12 = (2 * s1 * s2 + C2) / (s1 ** 2 + s2 ** 2 + C2)
+    return l12 * c12 * (s12 + C3) / (s1 * s2 + C3)
+
+
+def gene_metrics(imputed, measured, js=True):
+    """dict of per-gene float64 numpy vectors: PCC, cosine, RMSE (after zscore), SSIM (after scale_max), JS (after
+    scale_plus).  imputed / measured: [N, G] numpy or device tensors (raw = measured, impute = imputed in the
+    reference's naming)."""
+    dev = imputed.device if isinstance(imputed, torch.Tensor) else (
+        measured.device if isinstance(measured, torch.Tensor) else torch.device("cuda:0"))
+    x = torch.as_tensor(np.asarray(measured, dtype=np.float32) if not isinstance(measured, torch.Tensor) else measured)
+    y = torch.as_tensor(np.asarray(imputed, dtype=np.float32) if not isinstance(imputed, torch.Tensor) else imputed)
+    x, y = x.float().to(dev).contiguous(), y.float().to(dev).contiguous()
+    m = column_moments(x, y)
+    pcc = _pearson(m)
+    out = {"PCC": pcc}
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out["cosine"] = m["sxy"] / np.sqrt(m["sxx"] * m["syy"])
+        # zscore (ddof 0) of both columns: mean((zx - zy)^2) = 2 - 2 r
+        out["RMSE"] = np.sqrt(np.maximum(2.0 - 2.0 * pcc, 0.0))
+        out["SSIM"] = _ssim_scale_max(m)
+    if js:
+        N, G = x.shape
+        ch = _chunks(N)
+        with np.errstate(divide="ignore"):
+            ix = torch.from_numpy(1.0 / m["sx"]).to(dev)
+            iy = torch.from_numpy(1.0 / m["sy"]).to(dev)
+        part = torch.empty((ch, G), device=dev, dtype=torch.float64)
+        check(lib().stdiff_column_js(ptr(x), x.stride(0), ptr(y), y.stride(0), ptr(ix), ptr(iy), ptr(part), ch, N, G,
+                                     stream()))
+        p = part.cpu().numpy()
+        acc = np.zeros(G)
+        for c in range(ch):
+            acc += p[c]
+        out["JS"] = acc
+    return out

@@ -235,6 +235,38 @@ def test_cv_driver_flow(tmp_path):
     assert np.array_equal(host, a)
 
 
+def test_gene_metrics_match_scipy():
+    """device-side per-gene PCC / cosine / RMSE(zscore) / SSIM(scale_max) / JS(scale_plus) against the
+    reference's host formulas (test-stDiff.py:203-364, restated with numpy/scipy in float64)."""
+    import scipy.stats as sst
+    from stdiff_amd.metrics import gene_metrics
+    N, G = 1337, 70
+    raw = O.synth_expression(N, G, 4).astype(np.float32)
+    imp = np.clip(raw + 0.15 * np.random.default_rng(0).standard_normal((N, G)).astype(np.float32), 0, None) + 1e-3
+    got = gene_metrics(torch.from_numpy(imp).to(DEV), torch.from_numpy(raw).to(DEV))
+    r64, i64 = raw.astype(np.float64), imp.astype(np.float64)
+    ref = {k: np.zeros(G) for k in ("PCC", "cosine", "RMSE", "SSIM", "JS")}
+    for g in range(G):
+        a, b = r64[:, g], i64[:, g]
+        ref["PCC"][g] = sst.pearsonr(a, b)[0]
+        ref["cosine"][g] = a @ b / np.sqrt((a @ a) * (b @ b))
+        ref["RMSE"][g] = np.sqrt(((sst.zscore(a) - sst.zscore(b)) ** 2).mean())
+        a1, b1 = a / a.max(), b / b.max()                              # scale_max + cal_ssim with M = 1
+        mu1, mu2 = a1.mean(), b1.mean()
+        s1, s2 = np.sqrt(((a1 - mu1) ** 2).mean()), np.sqrt(((b1 - mu2) ** 2).mean())
+        s12 = ((a1 - mu1) * (b1 - mu2)).mean()
+        C1, C2 = 0.01 ** 2, 0.03 ** 2
+        ref["SSIM"][g] = ((2 * mu1 * mu2 + C1) / (mu1 ** 2 + mu2 ** 2 + C1)) * ((2 * s1 * s2 + C2) / (s1 ** 2 + s2 ** 2 + C2)) \
+            * ((s12 + C2 / 2) / (s1 * s2 + C2 / 2))
+        p, q = a / a.sum(), b / b.sum()
+        mm = (p + q) / 2
+        ref["JS"][g] = 0.5 * sst.entropy(p, mm) + 0.5 * sst.entropy(q, mm)
+    for k in ref:
+        assert np.allclose(got[k], ref[k], rtol=1e-9, atol=1e-10), (k, np.abs(got[k] - ref[k]).max())
+    again = gene_metrics(imp, raw)                                     # numpy inputs, deterministic
+    assert all(np.array_equal(again[k], got[k]) for k in got)
+
+
 def test_errors_and_quirks():
     from stdiff_amd.model.stDiff_model import DiT_stDiff
     from stdiff_amd.model.sample import sample_stDiff
