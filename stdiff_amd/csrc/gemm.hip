@@ -693,7 +693,11 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
         }
     }
     dim3 grid(p.tiles_m * p.tiles_n * p.ksplit), block(tile == 1 ? NT : 512);
-    if (tile == 3) grid.x = min((int)grid.x, cu_count());      // persistent: one workgroup per CU walks the tiles
+    if (tile == 3) {                                           // persistent: one workgroup per CU walks the tiles
+        int cus = cu_count();
+        if (const char* e = getenv("STDIFF_GEMM_CUS")) { const int v = atoi(e); if (v > 0 && v < cus) cus = v; }
+        grid.x = min((int)grid.x, cus);
+    }
     if (!bf)
         hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
     else if (tile == 1)
