@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define STDIFF_ABI_VERSION 2
+#define STDIFF_ABI_VERSION 3
 
 enum { STDIFF_F32 = 0, STDIFF_BF16 = 1 };
 
@@ -56,6 +56,7 @@ const char* stdiff_error_string(int status);
  * A and W share a_dtype; K % 64 == 0 (bf16) or K % 16 == 0 (f32); lda/ldw multiples of 8 (bf16) / 4 (f32)
  * elements and A/W 16-byte aligned; M, N arbitrary. gate has a_dtype, res is fp32.  With ANY epilogue a non-NULL
  * C2 (a_dtype, ldc2) additionally receives v itself -- the training forward keeps pre-activations / branch outputs. */
+enum { STDIFF_ROW_MAJOR = 0, STDIFF_K_MAJOR = 1 };
 typedef struct {
     int M, N, K;
     const void* A; int lda; int a_dtype;
@@ -70,6 +71,12 @@ typedef struct {
      * long K (the batch-sized GEMMs of a training step) are cut along K into partial products there and summed in a
      * fixed order by a second kernel that applies the epilogue: deterministic, no atomics. */
     void* workspace; long long workspace_bytes;
+    /* operand layouts (0 = STDIFF_ROW_MAJOR: [M][K] / [N][K] as above; 1 = STDIFF_K_MAJOR: the operand is [K][M] resp.
+     * [K][N] with lda / ldw the stride of a k-row).  The backward contractions dW = dY^T X (both K-major: K = the
+     * batch) and dX = dY W (W K-major) run without transposed copies.  k_valid (0 = K): rows k >= k_valid of K-major
+     * operands count as zero, so a batch that is not a multiple of the K-slab needs no padded copy either; row-major
+     * operands must then really have K columns. */
+    int a_layout, w_layout, k_valid;
 } stdiff_gemm_args;
 int stdiff_gemm(const stdiff_gemm_args* a, void* stream);
 

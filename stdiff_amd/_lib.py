@@ -24,7 +24,8 @@ class GemmArgs(C.Structure):
                 ("gate", vp), ("ldgate", i32),
                 ("res", vp), ("ldres", i32),
                 ("C2", vp), ("ldc2", i32),
-                ("workspace", vp), ("workspace_bytes", C.c_longlong)]
+                ("workspace", vp), ("workspace_bytes", C.c_longlong),
+                ("a_layout", i32), ("w_layout", i32), ("k_valid", i32)]
 
 
 class StepArgs(C.Structure):
@@ -109,7 +110,7 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.stdiff_abi_version() != 2:
+        if L.stdiff_abi_version() != 3:
             raise RuntimeError("libstdiff_hip.so ABI version mismatch")
         _lib = L
     return _lib

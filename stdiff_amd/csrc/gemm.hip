@@ -50,6 +50,7 @@ struct Params {
     void* C2; int ldc2;
     int vec;  // every epilogue pointer / stride allows aligned 4-wide (16 B fp32, 8 B bf16) access and N % 8 == 0
     int tiles_m, tiles_n;
+    int k_valid;         // K-major operands: rows k >= k_valid are zero (K itself is padded to the slab size)
     int ksplit, nk_per;  // split-K (128 x 128 kernel): grid = tiles * ksplit, split s covers K-slabs [s*nk_per, ..)
     float* ws; int ldws; // partial products [ksplit][M][ldws] fp32
 };
@@ -173,7 +174,13 @@ __device__ __forceinline__ void epi_rows128(const Params& p, const float* cl, in
     }
 }
 
-template <typename T>
+// AK / WK: the operand is given K-MAJOR ([K][M] resp. [K][N], the non-contracted index contiguous) instead of
+// [M][K] / [N][K].  That is how the backward contractions see their operands (dW = dY^T X: both; dX = dY W: W), so
+// no transposed copies are made: the tile is staged as [k][m] rows (32-byte / 64-byte column units XOR-swizzled by
+// the row) and the MFMA fragments come from ds_read_b64_tr_b16 (bf16: the hardware transposes a 4-row x 16-column
+// block per 16 lanes) or scalar LDS reads (fp32).  Rows k >= k_valid are staged as zeros (a batch that is not a
+// multiple of the K-slab).
+template <typename T, bool AK, bool WK>
 __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
     using C = Cfg<T>;
     constexpr int BK = C::BK, EPV = C::EPV, NSLOT = C::NSLOT, ROWB = C::ROWB;
@@ -193,31 +200,64 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
     const int wm = wid >> 1, wn = wid & 1;
 
     // ---- staging addresses (rows past the edge are clamped: their products are never stored)
+    constexpr int PPR = BM / EPV;                  // K-major: 16-byte pieces per k-row of the tile
     const T* ga[LPT];
     const T* gw[LPT];
-    int soff[LPT];
+    int soffa[LPT], soffw[LPT];
+    bool cva[LPT], cvw[LPT];                       // K-major: the piece's columns exist
+    auto kmajor_off = [](int k, int piece) {       // LDS byte offset of a 16-byte piece of row k
+        if constexpr (sizeof(T) == 2) return k * 256 + ((((piece >> 1) ^ ((k & 3) | (((k >> 3) & 1) << 2))) << 5) | ((piece & 1) << 4));
+        else return k * 512 + ((((piece >> 2) ^ ((k >> 2) & 3)) << 6) | ((piece & 3) << 4));
+    };
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
         int c = tid + NT * i;
         int row = c / NSLOT, slot = c % NSLOT;
-        ga[i] = (const T*)p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + slot * EPV;
-        gw[i] = (const T*)p.W + (size_t)min(n0 + row, p.N - 1) * p.ldw + slot * EPV;
-        soff[i] = row * ROWB + ((slot ^ C::swz(row)) << 4);
+        int krow = c / PPR, piece = c % PPR;
+        if constexpr (AK) {
+            cva[i] = m0 + piece * EPV < p.M;
+            ga[i] = (const T*)p.A + (size_t)krow * p.lda + m0 + piece * EPV;
+            soffa[i] = kmajor_off(krow, piece);
+        } else {
+            cva[i] = true;
+            ga[i] = (const T*)p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + slot * EPV;
+            soffa[i] = row * ROWB + ((slot ^ C::swz(row)) << 4);
+        }
+        if constexpr (WK) {
+            cvw[i] = n0 + piece * EPV < p.N;
+            gw[i] = (const T*)p.W + (size_t)krow * p.ldw + n0 + piece * EPV;
+            soffw[i] = kmajor_off(krow, piece);
+        } else {
+            cvw[i] = true;
+            gw[i] = (const T*)p.W + (size_t)min(n0 + row, p.N - 1) * p.ldw + slot * EPV;
+            soffw[i] = row * ROWB + ((slot ^ C::swz(row)) << 4);
+        }
     }
     u32x4 ra[LPT], rw[LPT];
     auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            ra[i] = *(const u32x4*)(ga[i] + k0);
-            rw[i] = *(const u32x4*)(gw[i] + k0);
+            const int krow = (tid + NT * i) / PPR;
+            if constexpr (AK) {
+                ra[i] = u32x4{0u, 0u, 0u, 0u};
+                if (cva[i] && k0 + krow < p.k_valid) ra[i] = *(const u32x4*)(ga[i] + (size_t)k0 * p.lda);
+            } else {
+                ra[i] = *(const u32x4*)(ga[i] + k0);
+            }
+            if constexpr (WK) {
+                rw[i] = u32x4{0u, 0u, 0u, 0u};
+                if (cvw[i] && k0 + krow < p.k_valid) rw[i] = *(const u32x4*)(gw[i] + (size_t)k0 * p.ldw);
+            } else {
+                rw[i] = *(const u32x4*)(gw[i] + k0);
+            }
         }
     };
     auto sstore = [&](int buf) {
         unsigned char* b = smem + buf * 2 * TILEB;
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            *(u32x4*)(b + soff[i]) = ra[i];
-            *(u32x4*)(b + TILEB + soff[i]) = rw[i];
+            *(u32x4*)(b + soffa[i]) = ra[i];
+            *(u32x4*)(b + TILEB + soffw[i]) = rw[i];
         }
     };
 
@@ -239,8 +279,25 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
                 for (int t = 0; t < 4; ++t) {
                     int ra_ = wm * 64 + t * 16 + fr, rw_ = wn * 64 + t * 16 + fr;
                     int slot = ks * 4 + fq;
-                    af[t] = *(const bf16x8*)(ba + ra_ * ROWB + ((slot ^ C::swz(ra_)) << 4));
-                    wf[t] = *(const bf16x8*)(bw + rw_ * ROWB + ((slot ^ C::swz(rw_)) << 4));
+                    // K-major: lanes (fr>>2, fr&3) of a 16-lane group address a 4-row x 16-column block whose rows are
+                    // k = 32 ks + 8 fq + {0..3} (then +4); the transposed read hands lane fr column fr of that block
+                    const int kb = ks * 32 + 8 * fq + (fr >> 2), fk = (kb & 3) | (((kb >> 3) & 1) << 2);
+                    if constexpr (AK) {
+                        const unsigned char* a0 = ba + kb * 256 + ((((wm * 64 + t * 16) >> 4) ^ fk) << 5) + 8 * (fr & 3);
+                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a0);
+                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 4 * 256));
+                        af[t] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    } else {
+                        af[t] = *(const bf16x8*)(ba + ra_ * ROWB + ((slot ^ C::swz(ra_)) << 4));
+                    }
+                    if constexpr (WK) {
+                        const unsigned char* w0 = bw + kb * 256 + ((((wn * 64 + t * 16) >> 4) ^ fk) << 5) + 8 * (fr & 3);
+                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)w0);
+                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(w0 + 4 * 256));
+                        wf[t] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    } else {
+                        wf[t] = *(const bf16x8*)(bw + rw_ * ROWB + ((slot ^ C::swz(rw_)) << 4));
+                    }
                 }
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
@@ -253,8 +310,20 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 int ra_ = wm * 64 + t * 16 + fr, rw_ = wn * 64 + t * 16 + fr;
-                af[t] = *(const f32x4*)(ba + ra_ * ROWB + ((fq ^ C::swz(ra_)) << 4));
-                wf[t] = *(const f32x4*)(bw + rw_ * ROWB + ((fq ^ C::swz(rw_)) << 4));
+                if constexpr (AK) {            // element kk of lane (fr, fq) is k = 4 fq + kk: row 4 fq + kk, column ra_
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        af[t][kk] = *(const float*)(ba + (4 * fq + kk) * 512 + ((((wm * 64 + t * 16) >> 4) ^ fq) << 6) + fr * 4);
+                } else {
+                    af[t] = *(const f32x4*)(ba + ra_ * ROWB + ((fq ^ C::swz(ra_)) << 4));
+                }
+                if constexpr (WK) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        wf[t][kk] = *(const float*)(bw + (4 * fq + kk) * 512 + ((((wn * 64 + t * 16) >> 4) ^ fq) << 6) + fr * 4);
+                } else {
+                    wf[t] = *(const f32x4*)(bw + rw_ * ROWB + ((fq ^ C::swz(rw_)) << 4));
+                }
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
@@ -640,7 +709,13 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
     const int bk = bf ? 64 : 16, epv = bf ? 8 : 4;
     if (a->K % bk) return STDIFF_ERR_SHAPE;
     if (a->lda % epv || a->ldw % epv || !al16(a->A) || !al16(a->W)) return STDIFF_ERR_ALIGN;
-    if (a->lda < a->K || a->ldw < a->K || a->ldc < a->N) return STDIFF_ERR_ARG;
+    const bool ak = a->a_layout == STDIFF_K_MAJOR, wk = a->w_layout == STDIFF_K_MAJOR;
+    STDIFF_CHECK_ARG((a->a_layout == STDIFF_ROW_MAJOR || ak) && (a->w_layout == STDIFF_ROW_MAJOR || wk));
+    const int k_valid = a->k_valid > 0 ? a->k_valid : a->K;
+    STDIFF_CHECK_ARG(k_valid <= a->K && (k_valid == a->K || ak || wk));
+    // K-major operands: [k_valid][M] resp. [k_valid][N], 16-byte column pieces (M resp. N a multiple of 8 / 4)
+    if ((ak && a->M % epv) || (wk && a->N % epv)) return STDIFF_ERR_SHAPE;
+    if ((ak ? a->lda < a->M : a->lda < a->K) || (wk ? a->ldw < a->N : a->ldw < a->K) || a->ldc < a->N) return STDIFF_ERR_ARG;
     if (a->epi == STDIFF_EPI_GATE_RES) STDIFF_CHECK_ARG(a->gate && a->res && a->c_dtype == STDIFF_F32);
     if (a->epi == STDIFF_EPI_ADD) STDIFF_CHECK_ARG(a->res != nullptr);
     if (a->epi == STDIFF_EPI_ACCUM) STDIFF_CHECK_ARG(a->c_dtype == STDIFF_F32);
@@ -678,6 +753,10 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
     const int bm = tile == 1 ? BM : 256, bn = tile == 1 ? BN : 256;
     p.tiles_m = cdiv(a->M, bm);
     p.tiles_n = cdiv(a->N, bn);
+    p.k_valid = k_valid;
+    if (ak || wk) tile = 1;                       // K-major staging exists in the 128 x 128 kernel only
+    p.tiles_m = cdiv(a->M, tile == 1 ? BM : 256);
+    p.tiles_n = cdiv(a->N, tile == 1 ? BN : 256);
     p.ksplit = 1; p.nk_per = a->K / bk; p.ws = nullptr; p.ldws = 0;
     if (tile == 1 && a->workspace && ((uintptr_t)a->workspace & 15) == 0) {
         // few tiles x long K (batch-sized training GEMMs): one block per tile would walk K alone on a mostly idle chip
@@ -698,10 +777,17 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
         if (const char* e = getenv("STDIFF_GEMM_CUS")) { const int v = atoi(e); if (v > 0 && v < cus) cus = v; }
         grid.x = min((int)grid.x, cus);
     }
+#define STDIFF_LAUNCH128(T)                                                                                    \
+    do {                                                                                                       \
+        if (ak && wk) hipLaunchKernelGGL((gemm_nt_kernel<T, true, true>), grid, block, 0, (hipStream_t)stream, p);        \
+        else if (ak) hipLaunchKernelGGL((gemm_nt_kernel<T, true, false>), grid, block, 0, (hipStream_t)stream, p);        \
+        else if (wk) hipLaunchKernelGGL((gemm_nt_kernel<T, false, true>), grid, block, 0, (hipStream_t)stream, p);        \
+        else hipLaunchKernelGGL((gemm_nt_kernel<T, false, false>), grid, block, 0, (hipStream_t)stream, p);               \
+    } while (0)
     if (!bf)
-        hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, block, 0, (hipStream_t)stream, p);
+        STDIFF_LAUNCH128(float);
     else if (tile == 1)
-        hipLaunchKernelGGL(gemm_nt_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, p);
+        STDIFF_LAUNCH128(bf16_t);
     else
         hipLaunchKernelGGL(gemm256p_kernel, grid, block, 0, (hipStream_t)stream, p);
     if (p.ksplit > 1) {

@@ -13,15 +13,30 @@ def round_up(a, b):
 
 
 def gemm(A, W, bias=None, out=None, out_dtype=None, epi=L.EPI_BIAS, gate=None, res=None, out2=None, M=None,
-         workspace=None):
-    """out[M,N] = epi(A[M,K] @ W[N,K]^T + bias). A/W: same dtype (fp32 or bf16), K-contiguous rows."""
+         workspace=None, a_kmajor=False, w_kmajor=False):
+    """out[M,N] = epi(A[M,K] @ W[N,K]^T + bias). A/W: same dtype (fp32 or bf16), K-contiguous rows -- or, with
+    a_kmajor / w_kmajor, given as [K, M] / [K, N] (K rows; need not be a multiple of the K-slab)."""
     require_gpu(A, W, bias, out, gate, res, out2, workspace)
-    M = A.shape[0] if M is None else M
-    N, K = W.shape[0], W.shape[1]
+    bk = 64 if A.dtype == torch.bfloat16 else 16
+    kA = A.shape[0] if a_kmajor else A.shape[1]
+    kW = W.shape[0] if w_kmajor else W.shape[1]
+    if a_kmajor and w_kmajor:
+        assert kA == kW
+        k_valid, K = kA, round_up(kA, bk)
+    elif a_kmajor or w_kmajor:
+        k_valid = kA if a_kmajor else kW            # the row-major operand carries the (zero-)padded K
+        K = kW if a_kmajor else kA
+        assert k_valid <= K, (k_valid, K)
+    else:
+        assert kA == kW
+        k_valid = K = kA
+    M = (A.shape[1] if a_kmajor else A.shape[0]) if M is None else M
+    N = W.shape[1] if w_kmajor else W.shape[0]
     if out is None:
         out = torch.empty((M, N), device=A.device, dtype=out_dtype or A.dtype)
     a = L.GemmArgs()
     a.M, a.N, a.K = M, N, K
+    a.a_layout, a.w_layout, a.k_valid = int(a_kmajor), int(w_kmajor), k_valid
     a.A, a.lda, a.a_dtype = ptr(A), A.stride(0), dt_of(A)
     a.W, a.ldw = ptr(W), W.stride(0)
     a.bias = ptr(bias)

@@ -62,13 +62,6 @@ class TrainCore:
         pw = self.pw
         self.G, self.Gp, self.H, self.depth, self.heads = pw.G, pw.Gp, pw.H, pw.depth, pw.heads
         self.tdt = pw.tdt
-        # ---- transposed operand copies W^T [in, out] for the dX = dY.W contractions
-        self.wT = {}
-        for n, w in pw.w.items():
-            if n in ("in_layer.0.weight", "cond_layer.0.weight", "time_emb.mlp.0.weight"):
-                continue
-            rows, cols = w.shape        # [out, in(padded)]
-            self.wT[n] = torch.empty((cols, ops.round_up(rows, 64)), device=dev, dtype=self.tdt)
         self.refresh_weights(pack=False)
         self._acts = {}
         # split-K scratch shared by every GEMM of the step (one stream, so uses never overlap): batch-sized outputs
@@ -76,11 +69,9 @@ class TrainCore:
         self.ws_splitk = torch.empty(16 << 20, device=dev, dtype=torch.float32)
 
     def refresh_weights(self, pack=True):
+        """fp32 master weights -> packed MFMA operands (the backward reads the same [out, in] copies K-major)."""
         if pack:
             self.pw.refresh()
-        for n, wt in self.wT.items():
-            w = self.pw.w[n]
-            ops.transpose(w, out=wt, rows_pad=wt.shape[1])
 
     def bucket_ranges(self):
         return bucket_ranges(self.offs, self.total, self.depth)
@@ -111,7 +102,6 @@ class TrainCore:
             deps=z(C, Gp), dh=z(C, H, dt=f32), dxn=z(C, H), dmod=z(C, 6 * H), dfmod=z(C, 2 * H), dbr=z(C, H),
             du=z(C, 4 * H), dupre=z(C, 4 * H), do=z(C, H), dqkv=z(C, 3 * H), delta=z(C, self.heads, dt=f32),
             ds32=z(C, H, dt=f32), dc=z(C, H, dt=f32), dcT_=z(C, H), de1=z(C, H), da1=z(C, H), dhT_=z(C, H),
-            tA=z(max(6 * H, Gp), Cp), tB=z(max(4 * H, Gp, 256), Cp), sT=z(H, Cp),
         )
         if len(self._acts) > 3:
             self._acts.clear()
@@ -164,22 +154,24 @@ class TrainCore:
         return a["eps"]
 
     # ------------------------------------------------------------------ backward
-    def _dW(self, a, name, dY, X=None, XT=None, rows=None):
-        """grad[name.weight] = dY^T X ; grad[name.bias] = colsum(dY).  K (= batch rows) zero-padded to Cp."""
-        C, Cp = a["C"], a["Cp"]
-        n_out = dY.shape[1]
-        dYT = ops.transpose(dY, out=a["tA"][:n_out], rows_pad=Cp)
-        if XT is None:
-            XT = ops.transpose(X, out=a["tB"][:X.shape[1]], rows_pad=Cp)
+    def _dW(self, a, name, dY, X, rows=None):
+        """grad[name.weight] = dY^T X ; grad[name.bias] = colsum(dY).  Both operands are read K-major ([batch, .]) as
+        they lie: no transposed copies, and a batch that is not a multiple of the K-slab is zero-extended in the kernel."""
         gw = self.g[name + ".weight"]
         m = gw.shape[0] if rows is None else rows
-        self._gemm(dYT[:m], XT[:gw.shape[1]], None, out=gw)
+        if m % 8 or gw.shape[1] % 8:         # odd gene counts: 16-byte column pieces do not exist, go through copies
+            Cp = a["Cp"]
+            dYT = ops.transpose(dY, rows_pad=Cp)
+            XT = ops.transpose(X, rows_pad=Cp)
+            self._gemm(dYT[:m], XT[:gw.shape[1]], None, out=gw)
+        else:
+            self._gemm(dY, X[:, :gw.shape[1]] if X.shape[1] != gw.shape[1] else X, None, out=gw, M=m, a_kmajor=True,
+                       w_kmajor=True)
         ops.colsum(dY[:, :m] if rows is not None else dY, self.g[name + ".bias"])
 
     def _dX(self, name, dY, out, epi=L.EPI_BIAS):
-        """out (+)= dY W  via the transposed operand copy W^T [in, out_pad]."""
-        wt = self.wT[name + ".weight"]
-        return self._gemm(dY, wt[:, :dY.shape[1]] if wt.shape[1] != dY.shape[1] else wt, None, out=out, epi=epi)
+        """out (+)= dY W  with W [out, in] read K-major (K = out features)."""
+        return self._gemm(dY, self.pw.w[name + ".weight"], None, out=out, epi=epi, w_kmajor=True)
 
     def backward(self, a, after_bucket=None):
         """a['deps'] holds d loss / d eps as the packed operand [C, Gp]; fills self.flat_g (overwrite).
@@ -192,8 +184,7 @@ class TrainCore:
         self._dX("out_layer.linear", deps, a["dxn"])
         ops.ln_modulate_bwd(a["dxn"], a["h"][D], a["meanf"], a["rstdf"], a["fmod"][:, H:2 * H], a["dh"],
                             a["dfmod"][:, 0:H], a["dfmod"][:, H:2 * H], accumulate=False)
-        sT = ops.transpose(a["s"], out=a["sT"], rows_pad=Cp)
-        self._dW(a, "out_layer.adaLN_modulation.1", a["dfmod"], XT=sT)
+        self._dW(a, "out_layer.adaLN_modulation.1", a["dfmod"], X=a["s"])
         self._dX("out_layer.adaLN_modulation.1", a["dfmod"], a["ds32"])
         if after_bucket:
             after_bucket(0)
@@ -219,7 +210,7 @@ class TrainCore:
             self._dX(p + "attn.qkv", a["dqkv"], a["dxn"])
             ops.ln_modulate_bwd(a["dxn"], a["h"][k], a["mean1"][k], a["rstd1"][k], mod[:, H:2 * H], a["dh"],
                                 dmod[:, 0:H], dmod[:, H:2 * H], accumulate=True)
-            self._dW(a, p + "adaLN_modulation.1", dmod, XT=sT)
+            self._dW(a, p + "adaLN_modulation.1", dmod, X=a["s"])
             self._dX(p + "adaLN_modulation.1", dmod, a["ds32"], epi=L.EPI_ACCUM)
             if after_bucket:
                 after_bucket(D - k)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert set(_lib._SIGS) == declared            # the ctypes table binds exactly the header's entry points
     L = _lib.lib()
-    assert L.stdiff_abi_version() == 2
+    assert L.stdiff_abi_version() == 3
     assert b"aligned" in L.stdiff_error_string(-3)
 
 

@@ -125,6 +125,34 @@ def test_gemm_split_k(ops, L, dt, M, N, K):
     assert relerr(ops.gemm(Ad, Wd, bd, out_dtype=torch.float32, workspace=small), v) < tol
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 40), (1000, 264, 512), (72, 1024, 300), (1024, 1024, 8)])
+def test_gemm_k_major_operands(ops, L, dt, M, N, K):
+    """Backward-pass layouts without transposed copies: A given as [K, M] and / or W as [K, N]; K (the batch) need not
+    be a multiple of the K-slab (rows >= k_valid count as zero).  Against the same contraction in fp32."""
+    A, W, b = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=K ** -0.5), rnd(N, seed=23, scale=0.1)
+    ref = q(A, dt) @ q(W, dt).T
+    Ad, Wd = to_dt(A, dt), to_dt(W, dt)
+    At, Wt = Ad.t().contiguous(), Wd.t().contiguous()                 # [K, M], [K, N]
+    tol = 3e-6 if dt == "fp32" else 3e-5
+    bk = 64 if dt == "bf16" else 16
+    Kp = (K + bk - 1) // bk * bk
+    pad = lambda x: torch.nn.functional.pad(x, (0, Kp - K)).contiguous()      # row-major operands carry the padded K
+    ws = torch.empty(4 << 20, device=DEV, dtype=torch.float32)
+    out = ops.gemm(At, Wt, None, out_dtype=torch.float32, a_kmajor=True, w_kmajor=True)            # dW = dY^T X
+    assert relerr(out, ref) < tol
+    assert relerr(ops.gemm(At, Wt, b.to(DEV), out_dtype=torch.float32, a_kmajor=True, w_kmajor=True, workspace=ws),
+                  ref + b) < tol
+    assert relerr(ops.gemm(pad(Ad), Wt, None, out_dtype=torch.float32, w_kmajor=True), ref) < tol   # dX = dY W
+    assert relerr(ops.gemm(At, pad(Wd), None, out_dtype=torch.float32, a_kmajor=True), ref) < tol
+    acc = rnd(M, N, seed=24).to(DEV)
+    base = acc.clone()
+    ops.gemm(pad(Ad), Wt, None, out=acc, epi=L.EPI_ACCUM, w_kmajor=True, workspace=ws)
+    assert relerr(acc, base.cpu() + ref) < tol
+    sub = ops.gemm(At, Wt, None, out_dtype=torch.float32, a_kmajor=True, w_kmajor=True, M=M - 8 if M > 8 else M)
+    assert relerr(sub, ref[:sub.shape[0]]) < tol                      # a row subset of a wider K-major operand
+
+
 @pytest.mark.parametrize("M,N,K", [(600, 520, 256), (257, 264, 64), (1024, 512, 1024)])
 def test_gemm_256_kernel_all_epilogues(ops, L, M, N, K, monkeypatch):
     """The persistent 256 x 256 bf16 kernel forced (STDIFF_GEMM_TILE=3 is read per call): ragged M / N edges, every
