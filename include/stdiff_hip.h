@@ -195,6 +195,7 @@ typedef struct {
     float* params; const float* grads; float* exp_avg; float* exp_avg_sq; int64_t n;
     const float* sumsq; int32_t* step_dev; float* scal;
     float max_norm, grad_scale, lr, beta1, beta2, eps, weight_decay;
+    void* bf16_mirror;   /* optional bf16 [n]: receives the updated parameters (the next forward's packed operands) */
 } stdiff_adamw_args;
 int stdiff_clip_adamw(const stdiff_adamw_args* a, void* stream);
 

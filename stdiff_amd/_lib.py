@@ -56,7 +56,7 @@ class AdamWArgs(C.Structure):
     _fields_ = [("params", vp), ("grads", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("n", i64),
                 ("sumsq", vp), ("step_dev", vp), ("scal", vp),
                 ("max_norm", f32), ("grad_scale", f32), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32),
-                ("weight_decay", f32)]
+                ("weight_decay", f32), ("bf16_mirror", vp)]
 
 
 _SIGS = {

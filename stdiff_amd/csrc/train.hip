@@ -195,9 +195,11 @@ __global__ void adam_prep_kernel(const float* sumsq, int32_t* step_dev, float* s
     scal[3] = norm;
 }
 
+// mirror (optional): bf16 copy of the updated parameters at the same flat offsets = the packed MFMA operands of the
+// next forward, written here (+2 B/param) instead of by a separate repack pass per weight (read 4 + write 2).
 __global__ __launch_bounds__(256) void clip_adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n,
                                                          const float* scal, float lr, float b1, float b2, float eps,
-                                                         float wd) {
+                                                         float wd, bf16_t* mirror) {
     const float coef = scal[0], step = scal[1], bc2_sqrt = scal[2];
     const int64_t nv = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* p, const float* 
         *(f32x4*)(p + 4 * i) = pp;
         *(f32x4*)(m + 4 * i) = mm;
         *(f32x4*)(v + 4 * i) = vv;
+        if (mirror) st4(mirror + 4 * i, pp);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
         for (int64_t i = nv * 4; i < n; ++i) {
@@ -222,6 +225,7 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(float* p, const float* 
             m[i] = m[i] * b1 + gr * (1.0f - b1);
             v[i] = v[i] * b2 + gr * gr * (1.0f - b2);
             p[i] -= step * (m[i] / (sqrtf(v[i]) / bc2_sqrt + eps));
+            if (mirror) mirror[i] = f2bf(p[i]);
         }
 }
 
@@ -372,13 +376,13 @@ extern "C" int stdiff_grad_sumsq(const float* grads, int64_t n, float* sumsq, vo
 extern "C" int stdiff_clip_adamw(const stdiff_adamw_args* a, void* stream) {
     STDIFF_CHECK_ARG(a && a->params && a->grads && a->exp_avg && a->exp_avg_sq && a->sumsq && a->step_dev && a->scal &&
                      a->n >= 0);
-    STDIFF_CHECK_ARG(al16(a->params) && al16(a->grads) && al16(a->exp_avg) && al16(a->exp_avg_sq));
+    STDIFF_CHECK_ARG(al16(a->params) && al16(a->grads) && al16(a->exp_avg) && al16(a->exp_avg_sq) && al8(a->bf16_mirror));
     if (a->n == 0) return STDIFF_OK;
     hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->sumsq, a->step_dev, a->scal,
                        a->max_norm, a->grad_scale, a->lr, a->beta1, a->beta2);
     hipLaunchKernelGGL(clip_adamw_kernel, dim3(ew_grid((size_t)a->n / 4 + 1)), dim3(256), 0, (hipStream_t)stream,
                        a->params, a->grads, a->exp_avg, a->exp_avg_sq, a->n, a->scal, a->lr, a->beta1, a->beta2,
-                       a->eps, a->weight_decay);
+                       a->eps, a->weight_decay, (bf16_t*)a->bf16_mirror);
     STDIFF_LAUNCH_STATUS();
     return STDIFF_OK;
 }

@@ -57,9 +57,18 @@ class PackedWeights:
         self.refresh()
         self._build_struct()
 
-    def refresh(self):
+    def refresh(self, skip=()):
         for name, buf in self.w.items():
-            ops.pack_rows(self.params[name].detach(), buf.shape[1], buf.dtype, out=buf)
+            if name not in skip:
+                ops.pack_rows(self.params[name].detach(), buf.shape[1], buf.dtype, out=buf)
+
+    def adopt(self, views):
+        """Replace operand buffers by caller-owned tensors of the same shape and dtype (the training engine's flat
+        mirror, which its optimizer kernel keeps current); rebuilds the C structs that hold their addresses."""
+        for name, t in views.items():
+            assert t.shape == self.w[name].shape and t.dtype == self.w[name].dtype and t.is_contiguous()
+            self.w[name] = t
+        self._build_struct()
 
     def b(self, name):
         return self.params[name].detach()

@@ -12,11 +12,12 @@ _NO_GRAD = ("condi_emb.weight",)      # unused by forward (stDiff_model.py:184,2
 
 
 def flat_layout(named_sizes):
-    """Offsets of each tensor in the flat fp32 buffer (every tensor starts on a 16-byte boundary) and its length."""
+    """Offsets of each tensor in the flat fp32 buffer and its length.  Every tensor starts on a multiple of 8 elements:
+    16-byte aligned in the fp32 buffers AND in the bf16 operand mirror that shares these offsets."""
     offs, total = {}, 0
     for n, numel in named_sizes:
         offs[n] = total
-        total += (numel + 3) // 4 * 4
+        total += (numel + 7) // 8 * 8
     return offs, total
 
 
@@ -62,7 +63,19 @@ class TrainCore:
         pw = self.pw
         self.G, self.Gp, self.H, self.depth, self.heads = pw.G, pw.Gp, pw.H, pw.depth, pw.heads
         self.tdt = pw.tdt
-        self.refresh_weights(pack=False)
+        # ---- operand copies kept current by the optimizer kernel instead of a repack pass per weight: bf16 compute
+        # reads a flat bf16 mirror (same offsets) that clip_adamw writes; fp32 compute reads the master weights in
+        # place.  Only the gene-padded in/cond weights ([H, Gp] != [H, G]) still go through pack_rows.
+        self.mirror = None
+        views = {}
+        if self.tdt == torch.bfloat16:
+            self.mirror = flat.to(torch.bfloat16)
+        for n in pw.w:
+            if pw.w[n].shape == params[n].shape:
+                src = self.mirror if self.mirror is not None else flat
+                views[n] = src[offs[n]:offs[n] + params[n].numel()].view_as(params[n])
+        pw.adopt(views)
+        self.mirrored = tuple(views)
         self._acts = {}
         # split-K scratch shared by every GEMM of the step (one stream, so uses never overlap): batch-sized outputs
         # have 32-200 tiles, too few to fill 256 CUs unless the long K axes are cut too
@@ -71,7 +84,7 @@ class TrainCore:
     def refresh_weights(self, pack=True):
         """fp32 master weights -> packed MFMA operands (the backward reads the same [out, in] copies K-major)."""
         if pack:
-            self.pw.refresh()
+            self.pw.refresh(skip=self.mirrored)
 
     def bucket_ranges(self):
         return bucket_ranges(self.offs, self.total, self.depth)
@@ -295,7 +308,7 @@ class TrainEngine(TrainCore):
         ops.grad_sumsq(self.flat_g, self.sumsq)
         ops.clip_adamw(self.flat_p, self.flat_g, self.m, self.v, self.sumsq, self.step_dev, self.scal, self.lr,
                        max_norm=self.max_norm, grad_scale=1.0 / self.world, betas=self.betas, eps=self.eps,
-                       weight_decay=self.wd)                                           # :78-80
+                       weight_decay=self.wd, bf16_mirror=self.mirror)                  # :78-80
         self.refresh_weights()
 
     def _step_graph(self, x, x_cond, noise, timesteps):
