@@ -208,9 +208,10 @@ extern "C" int stdiff_pack_rows(const float* src, int lds, void* dst, int ldd, i
 
 extern "C" int stdiff_gather_rows2(const float* a, int lda, const float* b, int ldb, const int64_t* idx, float* da,
                                    int ldda, float* db, int lddb, int R, int C, void* stream) {
-    STDIFF_CHECK_ARG(a && idx && da && R >= 0 && C > 0 && lda >= C && ldda >= C);
-    STDIFF_CHECK_ARG(!b || (db && ldb >= C && lddb >= C));
+    STDIFF_CHECK_ARG(R >= 0 && C > 0);
     if (R == 0) return STDIFF_OK;
+    STDIFF_CHECK_ARG(a && idx && da && lda >= C && ldda >= C);
+    STDIFF_CHECK_ARG(!b || (db && ldb >= C && lddb >= C));
     int vec = C % 4 == 0 && lda % 4 == 0 && ldda % 4 == 0 && al16(a) && al16(da);
     if (b) vec = vec && ldb % 4 == 0 && lddb % 4 == 0 && al16(b) && al16(db);
     hipLaunchKernelGGL(gather_rows2_kernel, dim3(std::min(cdiv(R, 4), 4096)), dim3(256), 0, (hipStream_t)stream, a, lda, b,
