@@ -316,6 +316,31 @@ def test_ddpm_step_bit_exact(ops, golden_dir):
         ns.step(out, torch.tensor(3), out, model_pred_type="v")
 
 
+def test_scheduler_api_completeness(ops):
+    """S3/S4/S7 of SURVEY 8(a): reconstruct_x0, q_posterior, undo and the linear / quadratic schedules through the
+    reference's method names, against the oracle's restatement."""
+    from stdiff_amd.model.stDiff_scheduler import NoiseScheduler
+    for sched in ("cosine", "linear", "quadratic"):
+        T = 60
+        ns = NoiseScheduler(T, beta_schedule=sched)
+        tb = O.make_tables(T, schedule=sched)
+        x, e = rnd(21, 36, seed=1), rnd(21, 36, seed=2)
+        for t in (T - 1, 7, 0):
+            x0 = ns.reconstruct_x0(x.to(DEV), t, e.to(DEV))
+            assert np.array_equal(x0.cpu().numpy(), O.reconstruct_x0(tb, x, t, e).numpy()), (sched, t)
+            mean = ns.q_posterior(x0, x.to(DEV), t)
+            assert np.array_equal(mean.cpu().numpy(), O.q_posterior(tb, x0.cpu(), x, t).numpy()), (sched, t)
+            v = ns.get_variance(torch.tensor(t))
+            assert float(v) == float(O.variance(tb, t))
+        torch.manual_seed(11)
+        und = ns.undo(None, x.to(DEV), None, 5)
+        torch.manual_seed(11)
+        z = torch.randn_like(x.to(DEV)).cpu()
+        beta = tb["betas"][5]
+        assert relerr(und, torch.sqrt(1 - beta) * x + torch.sqrt(beta) * z) < 1e-6
+        assert len(ns) == T
+
+
 def test_step_splice_and_ragged_width(ops):
     """G not a multiple of 4 (scalar path) + mask splice + packed operand refresh."""
     from stdiff_amd.model.stDiff_scheduler import NoiseScheduler

@@ -188,6 +188,26 @@ def test_tiny_and_empty_inputs():
     assert ops.gather_rows2(torch.zeros(4, 8, device=DEV), None, idx)[0].shape == (0, 8)
 
 
+def test_sample_x_start_mode_against_oracle():
+    """Q5: model_pred_type='x_start' through sample_stDiff (the step kernel skips reconstruct_x0)."""
+    from stdiff_amd.model.sample import sample_stDiff
+    from stdiff_amd.model.stDiff_scheduler import NoiseScheduler
+    from stdiff_amd.process.data import get_data_loader
+    G, H, depth, heads, T, N, B = 40, 128, 1, 4, 8, 50, 32
+    m, p = build(G, H, depth, heads, 13, "fp32")
+    mask = O.kfold_mask(G, 1)
+    gt = ((O.synth_expression(N, G, 2) * mask) * 2 - 1).astype(np.float32)
+    x_T = torch.randn(N, G, generator=torch.Generator().manual_seed(4)).numpy()
+    z = torch.randn(T, N, G, generator=torch.Generator().manual_seed(5)).numpy()
+    out = sample_stDiff(m, get_data_loader(gt, gt, batch_size=B, is_shuffle=False),
+                        NoiseScheduler(T, beta_schedule="cosine"), mask=mask, gt=gt, device=torch.device(DEV),
+                        num_step=T, sample_shape=(N, G), is_condi=True, sample_intermediate=T,
+                        model_pred_type='x_start', x_T=x_T, step_noise=z, is_tqdm=False)
+    ref = O.sample(p, O.make_tables(T, schedule="cosine"), torch.from_numpy(gt), torch.from_numpy(mask), B, heads, depth,
+                   torch.from_numpy(x_T), lambda t: torch.from_numpy(z[T - 1 - t]), T, T, "x_start")
+    assert relerr(out, ref) < 1e-4
+
+
 def test_sampler_world_size_invariance():
     """chunk-aligned shards with Philox keyed by the GLOBAL row reproduce the single-device run."""
     from stdiff_amd import engine as E
