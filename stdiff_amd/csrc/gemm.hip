@@ -1,15 +1,19 @@
 // NT GEMM on the gfx950 matrix cores:  C[M,N] = epi(A[M,K] . W[N,K]^T + bias[N]).
 //
 // Every dense contraction of the denoiser (nn.Linear: stDiff_model.py:18,20,54,56,107,128,132,177,180 and the
-// timm Mlp fc1/fc2), forward and backward, is this one shape: both operands are K-contiguous, so both tiles are
-// staged as [rows][K-slab] and both MFMA fragments are plain 16-byte LDS reads.  MFMA is issued "swapped" (the W
-// fragment as the A operand) so a lane ends up holding 4 CONSECUTIVE n of one m.
+// timm Mlp fc1/fc2) is this shape in the forward pass: both operands K-contiguous, both tiles staged as
+// [rows][K-slab], both MFMA fragments plain 16-byte LDS reads.  MFMA is issued "swapped" (the W fragment as the A
+// operand) so a lane ends up holding 4 CONSECUTIVE n of one m.  The backward contractions (dW = dY^T X, dX = dY W)
+// are the same product with one or both operands K-MAJOR; the 128 x 128 kernel reads those as they lie.
 //
 // Two kernels:
-//   gemm256p_kernel  bf16, 256 x 256 block tile, 8 waves, LDS-DMA staging, 4 phases per K-slab with counted waits and
-//                    two staggered wave groups (details above the kernel).  Used when the grid fills the chip.
-//   gemm_nt_kernel   bf16 or exact-fp32, 128 x 128 tile, 4 waves, register-staged double buffer, 2 blocks per CU.
-//                    bf16: v_mfma_f32_16x16x32_bf16;  f32: v_mfma_f32_16x16x4_f32 (a k-ordered fp32 fmaf chain).
+//   gemm256p_kernel  bf16, 256 x 256 block tile, 8 waves, persistent (one workgroup per CU walks the tiles), LDS-DMA
+//                    staging, 4 phases per K-slab with counted waits and two staggered wave groups (details above
+//                    the kernel).  Used when the output has >= 128 tiles.
+//   gemm_nt_kernel   bf16 or exact-fp32, 128 x 128 tile, 4 waves, register-staged double buffer, 2 blocks per CU;
+//                    optional K-major operands (transposed LDS reads) and deterministic split-K through a caller
+//                    workspace.  bf16: v_mfma_f32_16x16x32_bf16;  f32: v_mfma_f32_16x16x4_f32 (a k-ordered fp32
+//                    fmaf chain).
 // Both send the accumulators through an fp32 LDS image of the C tile so that the epilogue (bias / SiLU / GELU-erf /
 // gate*v+res / +res / accumulate / save-pre-activation) loads and stores whole row pieces, in batches whose latencies
 // overlap.  The epilogue math is a compile-time template parameter dispatched ONCE per block: a runtime switch inside

@@ -7,7 +7,6 @@ the scanpy clustering scores."""
 import numpy as np
 import torch
 
-from . import ops
 from ._lib import check, lib, ptr, require_gpu, stream
 
 

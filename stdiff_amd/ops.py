@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from ._lib import BF16, F32, check, dt_of, lib, ptr, require_gpu, stream
+from ._lib import F32, check, dt_of, lib, ptr, require_gpu, stream
 
 
 def round_up(a, b):

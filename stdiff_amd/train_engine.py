@@ -5,7 +5,6 @@ backend "nccl"), one bucket per DiT block, overlapped with the rest of the backw
 import torch
 
 from . import _lib as L
-from . import engine as E
 from . import ops
 
 _NO_GRAD = ("condi_emb.weight",)      # unused by forward (stDiff_model.py:184,236): no gradient, skipped by clip/AdamW
@@ -190,7 +189,6 @@ class TrainCore:
         """a['deps'] holds d loss / d eps as the packed operand [C, Gp]; fills self.flat_g (overwrite).
         after_bucket(i) is called when the i-th range of bucket_ranges() is final (DDP overlap)."""
         H, D = self.H, self.depth
-        Cp = a["Cp"]
         deps = a["deps"]
         # ---- final layer
         self._dW(a, "out_layer.linear", deps, X=a["xnf"], rows=self.G)
