@@ -127,6 +127,13 @@ int stdiff_pack_rows(const float* src, int lds, void* dst, int ldd, int dtype, i
 int stdiff_gather_rows2(const float* a, int lda, const float* b, int ldb, const int64_t* idx, float* da, int ldda,
                         float* db, int lddb, int R, int C, void* stream);
 
+/* Expression pre-processing per cell (test-stDiff.py:47-55: sc.pp.normalize_total(target_sum) -> sc.pp.log1p ->
+ * scale() = MaxAbsScaler over the cell's genes, process/data.py:79-83), with data_augment's fixed offset
+ * (process/data.py:86-100) as add_const:  y[r,:] = log1p((x[r,:] + add_const) * target_sum / rowsum) / rowmax.
+ * Zero-sum / zero-max rows divide by 1.  fp32, y may alias x. */
+int stdiff_preprocess_rows(const float* x, int ldx, float* y, int ldy, int R, int G, float add_const, float target_sum,
+                           void* stream);
+
 /* ---------------------------------------------------------------- diffusion arithmetic
  * One reverse step + known-gene splice, fused (NoiseScheduler.step, stDiff_scheduler.py:103-139 ->
  * reconstruct_x0 :68-78, q_posterior :80-90, get_variance :92-100; splice model/sample.py:94-95):

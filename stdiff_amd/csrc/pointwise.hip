@@ -140,6 +140,28 @@ __global__ __launch_bounds__(256) void gather_rows2_kernel(const float* __restri
     }
 }
 
+// Expression pre-processing of the reference driver, fused per cell (test-stDiff.py:47-55; process/data.py:79-100):
+//   [data_augment(fixed): + add_const]  ->  scanpy normalize_total(target_sum)  ->  log1p  ->  MaxAbsScaler over the
+//   cell's genes (scale() transposes, so the "feature" is the cell).  Zero-count cells divide by 1, as in scanpy /
+//   sklearn.  One wave per row, three sweeps (sum, max, write); the row is re-read from L2.
+__global__ __launch_bounds__(256) void preprocess_rows_kernel(const float* __restrict__ x, int ldx, float* y, int ldy,
+                                                              int R, int G, float add_const, float target_sum) {
+    const int lane = threadIdx.x & 63;
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += gridDim.x * 4) {
+        const float* xr = x + (size_t)r * ldx;
+        float s = 0.f;
+        for (int c = lane; c < G; c += 64) s += xr[c] + add_const;
+        s = wave_sum(s);
+        const float k = target_sum / (s == 0.f ? 1.f : s);
+        float mx = 0.f;
+        for (int c = lane; c < G; c += 64) mx = fmaxf(mx, fabsf(log1pf((xr[c] + add_const) * k)));
+        mx = wave_max(mx);
+        const float inv = 1.0f / (mx == 0.f ? 1.f : mx);
+        float* yr = y + (size_t)r * ldy;
+        for (int c = lane; c < G; c += 64) yr[c] = log1pf((xr[c] + add_const) * k) * inv;
+    }
+}
+
 inline int ew_grid(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 256 * 8); }
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -216,6 +238,17 @@ extern "C" int stdiff_gather_rows2(const float* a, int lda, const float* b, int 
     if (b) vec = vec && ldb % 4 == 0 && lddb % 4 == 0 && al16(b) && al16(db);
     hipLaunchKernelGGL(gather_rows2_kernel, dim3(std::min(cdiv(R, 4), 4096)), dim3(256), 0, (hipStream_t)stream, a, lda, b,
                        ldb, idx, da, ldda, db, lddb, R, C, vec);
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}
+
+extern "C" int stdiff_preprocess_rows(const float* x, int ldx, float* y, int ldy, int R, int G, float add_const,
+                                      float target_sum, void* stream) {
+    STDIFF_CHECK_ARG(R >= 0 && G > 0 && target_sum > 0.f);
+    if (R == 0) return STDIFF_OK;
+    STDIFF_CHECK_ARG(x && y && ldx >= G && ldy >= G);
+    hipLaunchKernelGGL(preprocess_rows_kernel, dim3(std::min(cdiv(R, 4), 8192)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       y, ldy, R, G, add_const, target_sum);
     STDIFF_LAUNCH_STATUS();
     return STDIFF_OK;
 }

@@ -337,6 +337,30 @@ def test_gene_metrics_match_scipy():
     assert all(np.array_equal(again[k], got[k]) for k in got)
 
 
+def test_preprocess_matches_numpy_restatement():
+    """data_augment(fixed) + normalize_total(1e4) + log1p + per-cell MaxAbs scale on the device against a
+    float64 numpy restatement of the scanpy / sklearn semantics (zero-count cells included)."""
+    from stdiff_amd.process.preprocess import normalize_log1p_scale, preprocess_pair
+    rng = np.random.default_rng(3)
+    counts = rng.poisson(rng.lognormal(0, 1, size=(1, 333)) * rng.lognormal(0, 0.5, size=(257, 1))).astype(np.float32)
+    counts[5] = 0                                                   # a cell without counts
+
+    def ref(c, add=0.0):
+        c = c.astype(np.float64) + add
+        tot = c.sum(1, keepdims=True)
+        tot[tot == 0] = 1.0
+        v = np.log1p(c / tot * 1e4)
+        mx = np.abs(v).max(1, keepdims=True)
+        mx[mx == 0] = 1.0
+        return v / mx
+    got = normalize_log1p_scale(torch.from_numpy(counts).to(DEV)).cpu().numpy()
+    assert np.abs(got - ref(counts)).max() < 2e-6 and got[5].max() == 0 and np.allclose(got.max(1)[:5], 1.0)
+    seq, sp = preprocess_pair(counts, counts[:100], noise_std=10.0, device=DEV)
+    assert seq.shape == (514, 333) and sp.shape == (100, 333)
+    assert np.abs(seq[:257] - ref(counts)).max() < 2e-6 and np.abs(seq[257:] - ref(counts, 10.0)).max() < 2e-6
+    assert np.abs(sp - ref(counts[:100])).max() < 2e-6
+
+
 def test_errors_and_quirks():
     from stdiff_amd.model.stDiff_model import DiT_stDiff
     from stdiff_amd.model.sample import sample_stDiff
