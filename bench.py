@@ -93,7 +93,7 @@ def measure_gemm_roofline(eng, ws, dtype, reps=3):
     tfile = os.path.join(ROOT, "profiles", "gemm_traffic.json")      # PMC-derived HBM bytes per launch, if collected
     if os.path.isfile(tfile):
         traffic = json.load(open(tfile)).get(dtype)
-    return {"bound": "mfma", "kernel": "gemm256p_kernel (+ gemm_nt_kernel<bf16> where its grid fits better)" if dtype == "bf16"
+    return {"bound": "mfma", "kernel": "gemm256q_kernel (+ gemm_nt_kernel<bf16> where its grid fits better)" if dtype == "bf16"
             else "gemm_nt_kernel<float>", "achieved": round(achieved, 1),
             "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK[dtype], 4), "traffic": traffic,
             "launches_per_step": len(launches), "avg_launch_us": round(avg_ms * 1e3, 1),

@@ -670,6 +670,204 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(Params p) {
     }
 }
 
+// ---- variant: two 32-MFMA phases per K-slab (see the loop comment); everything else as gemm256p_kernel
+__global__ __launch_bounds__(512, 1) void gemm256q_kernel(Params p) {
+    constexpr int ROWB = 128, HALF = 128 * ROWB;          // one half-tile = 128 rows x 64 bf16 = 16 KiB
+    __shared__ __attribute__((aligned(16))) unsigned char smem[9 * HALF];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int nk = p.K / 64;
+
+    // DMA sources: raw-buffer loads straight into LDS.  Half-tile h, piece q = 2*wid + i (8 rows): lane -> row
+    // 8q + (lane>>3), 16-byte K-chunk (lane&7) ^ row (the XOR swizzle sits on the source side: the LDS image is
+    // lane-linear).  The whole byte offset goes through the VGPR operand so that the descriptor's range check sees
+    // it: rows / columns past the edge read as zeros, no clamping.
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.A), 0, (int)(((unsigned)(p.M - 1) * p.lda + p.K) * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.W), 0, (int)(((unsigned)(p.N - 1) * p.ldw + p.K) * 2u), 0x00020000);
+    const int swl = ((lane & 7) ^ (lane >> 3)) << 3;
+    const unsigned voffA = (unsigned)((16 * wid + (lane >> 3)) * p.lda + swl) * 2u;
+    const unsigned voffW = (unsigned)((16 * wid + (lane >> 3)) * p.ldw + swl) * 2u;
+    unsigned sA = 0, sW = 0;       // byte offset of the tile's first row
+    auto set_tile = [&](int tile, int& m0, int& n0) {
+        int tm, tn;
+        tile_of(tile, ntiles, p.tiles_m, p.tiles_n, tm, tn);
+        m0 = tm * 256; n0 = tn * 256;
+        sA = (unsigned)m0 * (unsigned)p.lda * 2u;
+        sW = (unsigned)n0 * (unsigned)p.ldw * 2u;
+    };
+    auto dma = [&](int buf, int slot, int kt) {       // half-tile `slot` of K-slab kt into buffer buf
+        unsigned char* dst = smem + (buf * 4 + slot) * HALF + (2 * wid) * 1024;
+        const int h = slot & 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (slot < 2)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
+                                                         voffA + (sA + (unsigned)((h * 128 + i * 8) * p.lda + kt * 64) * 2u), 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16,
+                                                         voffW + (sW + (unsigned)((h * 128 + i * 8) * p.ldw + kt * 64) * 2u), 0, 0, 0);
+        }
+    };
+    auto prologue = [&]() {                           // slab 0 complete + A0 of slab 1
+        dma(0, 0, 0); dma(0, 2, 0); dma(0, 3, 0); dma(0, 1, 0);
+        if (nk > 1) dma(1, 0, 1);
+    };
+
+    // fragment read offsets inside a half-tile (row & 7 == fr & 7 for every fragment row)
+    int offA[2], offB[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int sl = ((ks * 4 + fq) ^ (fr & 7)) << 4;
+        offA[ks] = (wr * 64 + fr) * ROWB + sl;
+        offB[ks] = (wc * 32 + fr) * ROWB + sl;
+    }
+    bf16x8 af[4][2], bfr[2][2][2];
+    auto loadA = [&](int buf, int mh) {
+        const unsigned char* b = smem + (buf * 4 + mh) * HALF;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[mt][ks] = *(const bf16x8*)(b + offA[ks] + mt * 16 * ROWB);
+    };
+    auto loadB = [&](int buf, int nh) {
+        const unsigned char* b = smem + (buf * 4 + 2 + nh) * HALF;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) bfr[nh][nt][ks] = *(const bf16x8*)(b + offB[ks] + nt * 16 * ROWB);
+    };
+
+    f32x4 acc[2][2][4][2];
+
+#define STDIFF_MMA(MH, NH)                                                                                    \
+    do {                                                                                                      \
+        __builtin_amdgcn_s_setprio(1);                                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                      \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                      \
+        _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                      \
+            acc[MH][NH][mt][nt] =                                                                             \
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[NH][nt][ks], af[mt][ks], acc[MH][NH][mt][nt], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
+    } while (0)
+
+    // C quarter image (slots 5..8), XOR-swizzled 16-byte chunks
+    float* cl = (float*)(smem + 5 * HALF);
+    auto put = [&](auto MH, auto MP) {
+        constexpr int mh = decltype(MH)::value, mp = decltype(MP)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int row = wr * 32 + j * 16 + fr;
+                    const int chunk = nh * 32 + wc * 8 + nt * 4 + fq;
+                    *(f32x4*)(cl + row * 256 + ((chunk ^ fr) << 2)) = acc[mh][nh][2 * mp + j][nt];
+                }
+    };
+
+    int tile = blockIdx.x, m0, n0;
+    set_tile(tile, m0, n0);
+    prologue();
+    int iter = 0;
+    while (true) {
+        STDIFF_STAMP(0);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+        STDIFF_BARRIER();                              // every wave is done with the C image (slots 5..8)
+        if (nk > 1) { dma(1, 2, 1); dma(1, 3, 1); STDIFF_VMCNT(4); } else { STDIFF_VMCNT(0); }   // B0,B1 of slab 1
+        STDIFF_BARRIER();
+        STDIFF_STAMP(1);
+        if (wr == 1) STDIFF_BARRIER();                 // stagger the second wave group by one barrier
+
+        // Two phases per K-slab, 32 MFMAs each: P1 = A0 x (B0, B1), P2 = A1 x (B0, B1) with the B fragments of both
+        // column halves kept in registers (4 barriers per slab instead of 8, 24 LDS reads instead of 28).  Refills two
+        // slabs ahead: {A0,B0,B1}(t+2) in P2 of slab t (every wave has read them by then), A1(t+2) in P1 of slab t+1.
+        // Both counted waits are vmcnt(8) in steady state: they leave [A1 | A0 B0 B1 | A1] resp. [A1 | A0 B0 B1] in flight.
+        for (int t = 0; t < nk; ++t) {
+            const int b = t & 1, nb = b ^ 1;
+            const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+            // ---- P1: A0 x (B0, B1)
+            loadB(b, 0);
+            loadB(b, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            loadA(b, 0);
+            if (n1) { dma(nb, 1, t + 1); STDIFF_VMCNT(8); } else { STDIFF_VMCNT(0); }      // A1(t+1); retire A1(t)
+            STDIFF_BARRIER();
+            STDIFF_MMA(0, 0);
+            STDIFF_MMA(0, 1);
+            STDIFF_BARRIER();
+            // ---- P2: A1 x (B0, B1)
+            loadA(b, 1);
+            if (n2) { dma(b, 0, t + 2); dma(b, 2, t + 2); dma(b, 3, t + 2); STDIFF_VMCNT(8); }   // retire A0,B0,B1(t+1)
+            else if (n1) { STDIFF_VMCNT(2); }
+            STDIFF_BARRIER();
+            STDIFF_MMA(1, 0);
+            STDIFF_MMA(1, 1);
+            STDIFF_BARRIER();
+        }
+        if (wr == 0) STDIFF_BARRIER();                 // balance the stagger: every wave is past its last LDS read
+        STDIFF_STAMP(2);
+
+        const int em0 = m0, en0 = n0, next = tile + (int)gridDim.x;
+        if (next < ntiles) {                           // next tile's operands fly in under the epilogue
+            set_tile(next, m0, n0);
+            prologue();
+        }
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q) {
+            if (q) STDIFF_BARRIER();                   // image reads of the previous quarter are done
+            switch (q) {
+                case 0: put(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); break;
+                case 1: put(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); break;
+                case 2: put(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); break;
+                default: put(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}); break;
+            }
+            STDIFF_LGKMCNT0();
+            STDIFF_BARRIER();
+            if (p.vec) {
+#define STDIFF_CALL256(E)                                                                  \
+    do {                                                                                   \
+        if (p.c_bf16) {                                                                    \
+            if (p.C2) epi_quarter256<E, true, true>(p, cl, wid, lane, em0, en0, q);        \
+            else epi_quarter256<E, true, false>(p, cl, wid, lane, em0, en0, q);            \
+        } else {                                                                           \
+            if (p.C2) epi_quarter256<E, false, true>(p, cl, wid, lane, em0, en0, q);       \
+            else epi_quarter256<E, false, false>(p, cl, wid, lane, em0, en0, q);           \
+        }                                                                                  \
+    } while (0)
+                STDIFF_EPI_DISPATCH(STDIFF_CALL256)
+            } else {
+                const int rbase = em0 + (q >> 1) * 128 + (q & 1) * 32;
+#pragma unroll 1
+                for (int ps = 0; ps < 8; ++ps) {
+                    const int i = (tid >> 6) + 8 * ps, cq = tid & 63;
+                    const int gm = rbase + (i >> 5) * 64 + ((i >> 4) & 1) * 16 + (i & 15), gn = en0 + cq * 4;
+                    if (gm < p.M && gn < p.N)
+                        epilogue4_slow<bf16_t>(p, gm, gn, *(const f32x4*)(cl + i * 256 + ((cq ^ (i & 15)) << 2)));
+                }
+            }
+            STDIFF_LGKMCNT0();                         // image reads landed before the next put / next tile's DMA
+        }
+        STDIFF_STAMP(3);
+        ++iter;
+        if (next >= ntiles) break;
+        tile = next;
+    }
+}
+
 // ---------------------------------------------------------------- transpose (bf16 / f32), 64x64 tiles through LDS
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_kernel(const T* in, int ldi, T* out, int ldo, int rows, int cols,
@@ -755,6 +953,10 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
         tile = (b256 >= 128.0 || c256 <= c128) ? 3 : 1;
     }
     if (bf && (forced == 1 || forced == 3)) tile = forced;
+    // two 256 x 256 kernels: gemm256q (two 32-MFMA phases per slab) is the default, STDIFF_GEMM_TILE=3 selects the
+    // four-phase gemm256p it was derived from (A/B timing), 4 forces the default kernel for any shape
+    bool variant_q = forced != 3 && ((double)a->M + 256) * a->lda < 2.0e9 && ((double)a->N + 256) * a->ldw < 2.0e9;   // 32-bit DMA offsets
+    if (bf && forced == 4) tile = 3;
     const int bm = tile == 1 ? BM : 256, bn = tile == 1 ? BN : 256;
     p.tiles_m = cdiv(a->M, bm);
     p.tiles_n = cdiv(a->N, bn);
@@ -793,6 +995,8 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
         STDIFF_LAUNCH128(float);
     else if (tile == 1)
         STDIFF_LAUNCH128(bf16_t);
+    else if (variant_q)
+        hipLaunchKernelGGL(gemm256q_kernel, grid, block, 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(gemm256p_kernel, grid, block, 0, (hipStream_t)stream, p);
     if (p.ksplit > 1) {
