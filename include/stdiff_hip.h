@@ -219,6 +219,15 @@ int stdiff_column_moments(const float* x, int ldx, const float* y, int ldy, doub
 int stdiff_column_js(const float* x, int ldx, const float* y, int ldy, const double* inv_sum_x, const double* inv_sum_y,
                      double* partials, int chunks, int N, int G, void* stream);
 
+/* Spearman per gene (CalculateMeteics.SPCC :300-316, scipy.stats.spearmanr): xt / yt are the TRANSPOSED matrices
+ * ([G][ldt] fp32, gene g contiguous at g * ldt; stdiff_transpose makes them).  partials[g][b][3] (float64) = sums over
+ * the elements of block b (1024 consecutive cells) of rx'^2, ry'^2, rx' ry', rx' = average rank - (N+1)/2 (exact
+ * half-integers, ranks by counting).  blocks must be ceil(N / STDIFF_RANK_CELLS_PER_BLOCK); G <= 65535; cost grows as
+ * N^2 G.  rho_g = S_xy / sqrt(S_xx S_yy) with the blocks added in order. */
+#define STDIFF_RANK_CELLS_PER_BLOCK 1024
+int stdiff_rank_corr(const float* xt, const float* yt, long long ldt, double* partials, int blocks, int N, int G,
+                     void* stream);
+
 /* ---------------------------------------------------------------- whole-denoiser forward (inference)
  * DiT_stDiff.forward after the conditioning (stDiff_model.py:240-243): in_layer, depth x DiTblock, FinalLayer,
  * on R rows split into chunks (attention is per chunk).  Inputs: xp = packed x [R,Gp], s = silu(c) [R,H].

@@ -72,6 +72,7 @@ _SIGS = {
     "stdiff_gather_rows2": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, i32, i32, i32, vp]),
     "stdiff_column_moments": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, vp]),
     "stdiff_column_js": (i32, [vp, i32, vp, i32, vp, vp, vp, i32, i32, i32, vp]),
+    "stdiff_rank_corr": (i32, [vp, vp, i64, vp, i32, i32, i32, vp]),
     "stdiff_preprocess_rows": (i32, [vp, i32, vp, i32, i32, i32, f32, f32, vp]),
     "stdiff_ddpm_step": (i32, [C.POINTER(StepArgs), vp]),
     "stdiff_advance_timestep": (i32, [vp, vp]),

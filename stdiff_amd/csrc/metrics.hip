@@ -65,7 +65,84 @@ __global__ __launch_bounds__(256) void column_js_kernel(const float* __restrict_
     if (w == 0 && c < G) part[(size_t)blockIdx.y * G + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
+// Spearman (CalculateMeteics.SPCC, test-stDiff.py:300-316: scipy.stats.spearmanr = Pearson of the average ranks).
+// Ranks by counting instead of sorting: for element i of a column, lt = #{j: v_j < v_i}, le = #{j: v_j <= v_i}; the
+// average rank of its tie group is (lt + le + 1) / 2, and centred on the mean rank (N + 1) / 2 it is (lt + le - N) / 2:
+// integers, exact.  The columns arrive transposed ([G][ldt], one gene contiguous), a workgroup owns 1024 elements of one
+// gene in registers and streams the whole column through LDS (broadcast reads), 2 compares + 2 carry-adds per pair per
+// matrix: VALU-bound, N^2 G pairs (20 000 x 1000: 4e11 pairs).  One partial {sum rx'^2, sum ry'^2, sum rx' ry'} per
+// (gene, block), added on the host in block order.
+constexpr int RANK_I = 4;        // elements per thread
+constexpr int RANK_J = 2048;     // column values per LDS tile
+
+__global__ __launch_bounds__(256) void rank_corr_kernel(const float* __restrict__ xt, const float* __restrict__ yt,
+                                                        size_t ldt, double* __restrict__ part, int N) {
+    __shared__ __align__(16) float sx[RANK_J];
+    __shared__ __align__(16) float sy[RANK_J];
+    __shared__ double red[4][3];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float* xc = xt + (size_t)blockIdx.y * ldt;
+    const float* yc = yt + (size_t)blockIdx.y * ldt;
+    const int i0 = blockIdx.x * (256 * RANK_I);
+    float xi[RANK_I], yi[RANK_I];
+    int ltx[RANK_I], lex[RANK_I], lty[RANK_I], ley[RANK_I];
+#pragma unroll
+    for (int k = 0; k < RANK_I; ++k) {
+        const int i = i0 + k * 256 + tid;
+        xi[k] = i < N ? xc[i] : 0.f;
+        yi[k] = i < N ? yc[i] : 0.f;
+        ltx[k] = lex[k] = lty[k] = ley[k] = 0;
+    }
+    for (int j0 = 0; j0 < N; j0 += RANK_J) {
+        __syncthreads();
+        for (int j = tid; j < RANK_J; j += 256) {       // past the end: NaN compares false both ways
+            sx[j] = j0 + j < N ? xc[j0 + j] : NAN;
+            sy[j] = j0 + j < N ? yc[j0 + j] : NAN;
+        }
+        __syncthreads();
+        const int jn = min(RANK_J, (N - j0 + 3) & ~3);
+        for (int j = 0; j < jn; j += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(&sx[j]);
+            const float4 b = *reinterpret_cast<const float4*>(&sy[j]);
+#pragma unroll
+            for (int k = 0; k < RANK_I; ++k) {
+                ltx[k] += (a.x < xi[k]) + (a.y < xi[k]) + (a.z < xi[k]) + (a.w < xi[k]);
+                lex[k] += (a.x <= xi[k]) + (a.y <= xi[k]) + (a.z <= xi[k]) + (a.w <= xi[k]);
+                lty[k] += (b.x < yi[k]) + (b.y < yi[k]) + (b.z < yi[k]) + (b.w < yi[k]);
+                ley[k] += (b.x <= yi[k]) + (b.y <= yi[k]) + (b.z <= yi[k]) + (b.w <= yi[k]);
+            }
+        }
+    }
+    double sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+    for (int k = 0; k < RANK_I; ++k) {
+        if (i0 + k * 256 + tid < N) {
+            const double rx = 0.5 * (double)(ltx[k] + lex[k] - N), ry = 0.5 * (double)(lty[k] + ley[k] - N);
+            sxx += rx * rx; syy += ry * ry; sxy += rx * ry;
+        }
+    }
+    // fixed-order reduction: lanes by xor-butterfly (same tree every run), then the four waves in order
+    for (int o = 32; o; o >>= 1) {
+        sxx += __shfl_xor(sxx, o); syy += __shfl_xor(syy, o); sxy += __shfl_xor(sxy, o);
+    }
+    if (lane == 0) { red[w][0] = sxx; red[w][1] = syy; red[w][2] = sxy; }
+    __syncthreads();
+    if (tid < 3)
+        part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 + tid] =
+            (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
 }  // namespace
+
+extern "C" int stdiff_rank_corr(const float* xt, const float* yt, long long ldt, double* partials, int blocks, int N,
+                                int G, void* stream) {
+    STDIFF_CHECK_ARG(xt && yt && partials && N > 0 && G > 0 && ldt >= N && G <= 65535);
+    STDIFF_CHECK_ARG(blocks == cdiv(N, 256 * RANK_I));
+    hipLaunchKernelGGL(rank_corr_kernel, dim3(blocks, G), dim3(256), 0, (hipStream_t)stream, xt, yt, (size_t)ldt,
+                       partials, N);
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}
 
 extern "C" int stdiff_column_moments(const float* x, int ldx, const float* y, int ldy, double* partials, int chunks,
                                      int N, int G, void* stream) {

@@ -306,8 +306,8 @@ def test_cv_driver_flow(tmp_path):
 
 
 def test_gene_metrics_match_scipy():
-    """device-side per-gene PCC / cosine / RMSE(zscore) / SSIM(scale_max) / JS(scale_plus) against the
-    reference's host formulas (test-stDiff.py:203-364, restated with numpy/scipy in float64)."""
+    """device-side per-gene PCC / cosine / SPCC / RMSE(zscore) / SSIM(scale_max) / JS(scale_plus) against
+    the reference's host formulas (test-stDiff.py:203-364, restated with numpy/scipy in float64)."""
     import scipy.stats as sst
     from stdiff_amd.metrics import gene_metrics
     N, G = 1337, 70
@@ -315,10 +315,11 @@ def test_gene_metrics_match_scipy():
     imp = np.clip(raw + 0.15 * np.random.default_rng(0).standard_normal((N, G)).astype(np.float32), 0, None) + 1e-3
     got = gene_metrics(torch.from_numpy(imp).to(DEV), torch.from_numpy(raw).to(DEV))
     r64, i64 = raw.astype(np.float64), imp.astype(np.float64)
-    ref = {k: np.zeros(G) for k in ("PCC", "cosine", "RMSE", "SSIM", "JS")}
+    ref = {k: np.zeros(G) for k in ("PCC", "cosine", "SPCC", "RMSE", "SSIM", "JS")}
     for g in range(G):
         a, b = r64[:, g], i64[:, g]
         ref["PCC"][g] = sst.pearsonr(a, b)[0]
+        ref["SPCC"][g] = sst.spearmanr(a, b)[0]
         ref["cosine"][g] = a @ b / np.sqrt((a @ a) * (b @ b))
         ref["RMSE"][g] = np.sqrt(((sst.zscore(a) - sst.zscore(b)) ** 2).mean())
         a1, b1 = a / a.max(), b / b.max()                              # scale_max + cal_ssim with M = 1
@@ -335,6 +336,33 @@ def test_gene_metrics_match_scipy():
         assert np.allclose(got[k], ref[k], rtol=1e-9, atol=1e-10), (k, np.abs(got[k] - ref[k]).max())
     again = gene_metrics(imp, raw)                                     # numpy inputs, deterministic
     assert all(np.array_equal(again[k], got[k]) for k in got)
+
+
+@pytest.mark.parametrize("N", [1, 5, 1024, 1025, 4500])
+def test_spearman_ties_and_block_edges(N):
+    """Average ranks by counting (csrc/metrics.hip::rank_corr_kernel) against scipy.stats.spearmanr: heavy ties (count
+    data: most entries are zero), a column that is constant (nan, as scipy), row counts on both sides of the 1024-cell
+    block and the 2048-value LDS tile."""
+    import warnings
+    import scipy.stats as sst
+    from stdiff_amd.metrics import spearman
+    rng = np.random.default_rng(N)
+    G = 9
+    a = rng.poisson(0.7, size=(N, G)).astype(np.float32)
+    b = (a + rng.poisson(0.5, size=(N, G))).astype(np.float32)
+    a[:, 3] = rng.standard_normal(N)                                 # no ties
+    b[:, 3] = a[:, 3] ** 3 + 0.1 * rng.standard_normal(N)
+    b[:, 4] = -a[:, 4]                                               # rho = -1 (or nan when constant)
+    a[:, 5] = 2.0                                                    # constant column
+    got = spearman(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV))
+    for g in range(G):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = sst.spearmanr(a[:, g].astype(np.float64), b[:, g].astype(np.float64))[0] if N > 1 else np.nan
+        if np.isnan(ref):
+            assert np.isnan(got[g]), (g, got[g])
+        else:
+            assert abs(got[g] - ref) < 1e-12, (g, got[g], ref)
 
 
 def test_preprocess_matches_numpy_restatement():
