@@ -100,6 +100,44 @@ def measure_gemm_roofline(eng, ws, dtype, reps=3):
             "flops_per_launch": flops / len(launches)}
 
 
+def measure_hbm_kernels(eng, ws, sched, gt, mask, dtype, reps=10):
+    """Achieved HBM GB/s of the bandwidth-bound kernels of one reverse step at the full row count (HIP events on the
+    launch stream, `reps` launches each): algorithmic bytes (DESIGN.md section 4 / SURVEY 8d) / average duration."""
+    from stdiff_amd import ops
+    from stdiff_amd.engine import step_coefficients
+    R, dev = ws.R, ws.h.device
+    s_el = 2 if dtype == "bf16" else 4
+    ycond = torch.randn(R, H, device=dev)
+    temb = torch.randn(T, H, device=dev)
+    t_dev = torch.full((1,), T // 2, device=dev, dtype=torch.int32)
+    coef = step_coefficients(sched).to(dev)
+    x = torch.randn(R, G, device=dev)
+    ws.h.normal_()
+    ws.eps.normal_()
+    ws.mod.normal_()
+    cases = {
+        "ln_modulate_kernel": (lambda: ops.ln_modulate(ws.h, ws.mod[:, 0:H], ws.mod[:, H:2 * H], out=ws.xn),
+                               R * H * (4 + 3 * s_el)),
+        "silu_cond_kernel": (lambda: ops.silu_cond(ycond, temb=temb, t_index=t_dev, out=ws.s), R * H * (4 + s_el)),
+        "ddpm_step_kernel": (lambda: ops.ddpm_step(x, ws.eps, gt, mask, coef, t_dev, T // 2, seed=1, xp=ws.xp),
+                             R * G * (16 + s_el)),
+    }
+    out = {}
+    for name, (fn, nbytes) in cases.items():
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        us = a.elapsed_time(b) * 1e3 / reps
+        out[name] = {"bytes": nbytes, "us": round(us, 1), "GB/s": round(nbytes / us / 1e3, 1),
+                     "frac_of_8TB/s": round(nbytes / us / 1e3 / 8000.0, 3)}
+    return out
+
+
 def cpu_baseline(rows_chunks=8, steps=12):
     """The oracle (eager PyTorch fp32 restatement of the reference, oracle/cpu_ref.py) on the host cores, on a bounded
     sample of the same workload: `rows_chunks` chunks of 512 spots x 1000 genes, `steps` reverse steps."""
@@ -252,6 +290,8 @@ def main():
         with torch.no_grad():
             rec["roofline"] = measure_gemm_roofline(eng, eng.workspace(lens, lane=99), args.dtype)
         rec["roofline"]["whole_step_frac"] = round(rec["step_tflops"] / PEAK[args.dtype], 4)
+        with torch.no_grad():
+            rec["hbm_kernels"] = measure_hbm_kernels(eng, eng.workspace(lens, lane=99), sched, gt, mask, args.dtype)
         if world == 1 and not args.no_train:
             del smp
             torch.cuda.empty_cache()

@@ -103,9 +103,10 @@ __device__ __forceinline__ void epi_load(const Params& p, int gm, int gn, f32x4&
 
 template <int EPI, typename T>
 __device__ __forceinline__ void epi_store(const Params& p, int gm, int gn, f32x4 pre, f32x4 g, f32x4 r) {
-    const f32x4 o = epi_math<EPI>(pre, g, r);
-    if (p.c_bf16) st4((bf16_t*)p.C + (size_t)gm * p.ldc + gn, o);
-    else *(f32x4*)((float*)p.C + (size_t)gm * p.ldc + gn) = o;
+    // bf16 outputs take the polynomial GELU here too: every bf16 kernel then produces the same bits for the same
+    // row, whichever tile shape the host heuristic picks (chunk-, lane- and shard-invariance of the sampler)
+    if (p.c_bf16) st4((bf16_t*)p.C + (size_t)gm * p.ldc + gn, epi_math<EPI, true>(pre, g, r));
+    else *(f32x4*)((float*)p.C + (size_t)gm * p.ldc + gn) = epi_math<EPI, false>(pre, g, r);
     if (p.C2) st4((T*)p.C2 + (size_t)gm * p.ldc2 + gn, pre);       // v itself, in the operand dtype
 }
 
