@@ -468,6 +468,103 @@ __device__ __forceinline__ void epi_quarter256(const Params& p, const float* cl,
     }
 }
 
+// LDS accesses of the gate-residual tile epilogue are written as asm so that the compiler's conservative
+// s_waitcnt vmcnt(0) (LDS access while an LDS-DMA may be in flight) does not drain the prefetched side loads.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+__device__ __forceinline__ void lds_write16(unsigned addr, f32x4 v) {
+    asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 lds_read16(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+// Whole-tile epilogue of the two-phase kernel for out = res + gate * (acc + bias) (attn.proj / mlp.fc2: the fp32
+// residual stream).  Same quarter images as epi_quarter256, but the side inputs (gate: 8 B, res: 16 B per lane and
+// row) of batch b + 1 are requested BEFORE batch b is read from the image, converted and stored: their HBM latency
+// (8 batches per tile, ~1.5 us each when exposed) runs under the previous batch and under the put + barrier of the
+// next quarter.  Fully unrolled so that the two register sets are static.
+template <bool CBF>
+__device__ __forceinline__ void epi_tile256_gate_res(const Params& p, const f32x4 (&acc)[2][2][4][2], unsigned cla,
+                                                     int wid, int lane, int m0, int n0) {
+    asm volatile("" : "+v"(lane));       // per-lane offsets are recomputed per tile, not kept live across the K loop
+    const int wr = wid >> 2, wc = wid & 3, fr = lane & 15, fq = lane >> 4;
+    const int gn = n0 + lane * 4;
+    const bool colok = gn < p.N;
+    const int gnc = min(gn, p.N - 4);
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bias4 = *(const f32x4*)(p.bias + gnc);
+    u32x2 graw[2][4];
+    f32x4 r[2][4];
+    auto row_of = [&](int b, int ps) {                   // batch b = 2 * quarter + pb
+        const int q = b >> 1, i = wid + 8 * ((b & 1) * 4 + ps);
+        return m0 + (q >> 1) * 128 + (q & 1) * 32 + (i >> 5) * 64 + ((i >> 4) & 1) * 16 + (i & 15);
+    };
+    auto issue = [&](int b, int slot) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int gm = min(row_of(b, ps), p.M - 1);
+            graw[slot][ps] = *(const u32x2*)((const bf16_t*)p.gate + (size_t)gm * p.ldgate + gnc);
+            r[slot][ps] = *(const f32x4*)(p.res + (size_t)gm * p.ldres + gnc);
+        }
+    };
+    issue(0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q) STDIFF_BARRIER();                         // image reads of the previous quarter are done
+        const int mh = q >> 1, mp = q & 1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int row = wr * 32 + j * 16 + fr;
+                    const int chunk = nh * 32 + wc * 8 + nt * 4 + fq;
+                    lds_write16(cla + (unsigned)(row * 256 + ((chunk ^ fr) << 2)) * 4u, acc[mh][nh][2 * mp + j][nt]);
+                }
+        STDIFF_LGKMCNT0();
+        STDIFF_BARRIER();
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const int b = 2 * q + pb, slot = b & 1;
+            if (b + 1 < 8) issue(b + 1, slot ^ 1);
+            f32x4 v[4];
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int i = wid + 8 * (pb * 4 + ps);
+                v[ps] = lds_read16(cla + (unsigned)(i * 256 + ((lane ^ (i & 15)) << 2)) * 4u);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                f32x4 g;
+                g[0] = __builtin_bit_cast(float, graw[slot][ps][0] << 16);
+                g[1] = __builtin_bit_cast(float, graw[slot][ps][0] & 0xffff0000u);
+                g[2] = __builtin_bit_cast(float, graw[slot][ps][1] << 16);
+                g[3] = __builtin_bit_cast(float, graw[slot][ps][1] & 0xffff0000u);
+                v[ps] = r[slot][ps] + g * (v[ps] + bias4);
+                asm volatile("" : "+v"(v[ps]));          // keep the math out of the predicated blocks
+            }
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int gm = row_of(b, ps);
+                if (gm < p.M && colok) {
+                    if constexpr (CBF) {
+                        u32x2 rr;
+                        rr[0] = pack2bf(v[ps][0], v[ps][1]);
+                        rr[1] = pack2bf(v[ps][2], v[ps][3]);
+                        __builtin_nontemporal_store(rr, (u32x2*)((bf16_t*)p.C + (size_t)gm * p.ldc + gn));
+                    } else __builtin_nontemporal_store(v[ps], (f32x4*)((float*)p.C + (size_t)gm * p.ldc + gn));
+                }
+            }
+        }
+    }
+}
+
 // PERSISTENT: the grid is min(tiles, CUs) workgroups and each walks tiles b, b + grid, ...  The LDS holds 9 half-tile
 // slots (144 KiB): [buf0: A0 A1 B0 B1][buf1: A0 A1 B0 B1][extra]; the epilogue's fp32 C image (64 rows at a time) lives
 // in the LAST FOUR slots, so the next tile's prologue (slab 0 into buf0 and A0 of slab 1 into buf1.A0) is issued by
@@ -759,6 +856,7 @@ __global__ __launch_bounds__(512, 1) void gemm256q_kernel(Params p) {
 
     // C quarter image (slots 5..8), XOR-swizzled 16-byte chunks
     float* cl = (float*)(smem + 5 * HALF);
+    const unsigned cla = lds_addr(cl);
     auto put = [&](auto MH, auto MP) {
         constexpr int mh = decltype(MH)::value, mp = decltype(MP)::value;
 #pragma unroll
@@ -827,6 +925,10 @@ __global__ __launch_bounds__(512, 1) void gemm256q_kernel(Params p) {
             set_tile(next, m0, n0);
             prologue();
         }
+        if (p.vec && p.epi == STDIFF_EPI_GATE_RES && !p.C2) {
+            if (p.c_bf16) epi_tile256_gate_res<true>(p, acc, cla, wid, lane, em0, en0);
+            else epi_tile256_gate_res<false>(p, acc, cla, wid, lane, em0, en0);
+        } else
 #pragma unroll 1
         for (int q = 0; q < 4; ++q) {
             if (q) STDIFF_BARRIER();                   // image reads of the previous quarter are done
