@@ -217,9 +217,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # STDIFF_BENCH_REHEARSAL=1: run the N-rank plumbing (launcher env, barriers, max-over-ranks, rank-0 line) on a box
+    # with ONE GPU: every rank uses cuda:0 and the process group is gloo.  Numbers from such a run mean nothing.
+    rehearsal = os.environ.get("STDIFF_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
 
@@ -278,7 +286,8 @@ def main():
     rec = {
         "metric": "imputed spots/sec (1000-step DDPM sampling)", "value": round(value, 2), "unit": "spots/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+        "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, not a measurement)",
         "config": {"workload": f"BASELINE configs[1]: {R} spots x {G} genes per GPU, hidden {H}, depth {DEPTH}, "
                                f"{HEADS} heads, chunks of {BATCH}, cosine T={T}; value = spots / (1000 x measured "
                                f"seconds per reverse step)", "parallelism": f"spot-sharded x{world}, no collective",
