@@ -177,27 +177,38 @@ def cpu_baseline(rows_chunks=8, steps=12):
             "train_sample": f"{tsteps} training iterations of {BATCH} cells (forward, masked MSE, backward, clip, AdamW)"}
 
 
-def train_throughput(dtype, dev, steps=20, warmup=5):
+def train_throughput(dtype, dev, steps=20, warmup=5, dist=None, rank=0, world=1):
     """train cells/s = cells through one full iteration (add-noise, forward, masked MSE, backward,
-    clip, AdamW, operand repack) per second, steady state, reference batch of 512 cells at the cfg2 model."""
+    clip, AdamW, operand repack) per second, steady state, reference batch of 512 cells PER RANK at the cfg2 model.
+    With a process group (world > 1) this is data-parallel training: every rank steps on its own batch,
+    the flat gradient is all-reduced in depth+2 buckets issued between the backward segments, and the time is the
+    max over ranks; cells/s counts the cells of all ranks."""
     from stdiff_amd import synth as O
     from stdiff_amd.train_engine import TrainEngine
     model = build_model(dtype, dev)
     eng = TrainEngine(model, lr=1e-4, diffusion_step=T, mask=O.kfold_mask(G, 0))
-    st = torch.from_numpy(O.synth_expression(8 * BATCH, G, 1) * 2 - 1).to(dev)
+    assert eng.world == world
+    st = torch.from_numpy(O.synth_expression(8 * BATCH, G, 1 + rank) * 2 - 1).to(dev)
     for i in range(warmup):
         eng.step(st[:BATCH], st[:BATCH])
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         lo = (i % 8) * BATCH
         eng.step(st[lo:lo + BATCH], st[lo:lo + BATCH])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
     loss = float(eng.loss)
     assert loss == loss, "non-finite training loss"
-    return {"cells_per_s": round(BATCH / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch": BATCH, "dtype": dtype,
-            "tflops": round(3 * BATCH * (6 * G * H + 512 * H + 222 * H * H + 24 * BATCH * H) / dt / 1e12, 1)}
+    return {"cells_per_s": round(world * BATCH / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch_per_rank": BATCH,
+            "ranks": world, "dtype": dtype, "grad_allreduce_MB": round(eng.total * 4 / 1e6, 1) if world > 1 else 0,
+            "tflops": round(world * 3 * BATCH * (6 * G * H + 512 * H + 222 * H * H + 24 * BATCH * H) / dt / 1e12, 1)}
 
 
 def main():
@@ -220,6 +231,9 @@ def main():
     # STDIFF_BENCH_REHEARSAL=1: run the N-rank plumbing (launcher env, barriers, max-over-ranks, rank-0 line) on a box
     # with ONE GPU: every rank uses cuda:0 and the process group is gloo.  Numbers from such a run mean nothing.
     rehearsal = os.environ.get("STDIFF_BENCH_REHEARSAL") == "1"
+    if os.environ.get("STDIFF_BENCH_DUMP"):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["STDIFF_BENCH_DUMP"]), exit=False)
     if rehearsal:
         local = 0
     if world > 1:
@@ -307,6 +321,29 @@ def main():
             rec["train"] = train_throughput(args.dtype, dev)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
+    if world > 1 and not args.no_train:
+        # secondary metric on N ranks: data-parallel training.  A watchdog on every rank guarantees that rank 0 still
+        # prints its line (without this leg) should a collective ever stall: the headline number is already measured.
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(120):
+                if rank == 0:
+                    rec["train"] = {"error": "data-parallel training leg did not finish within 120 s"}
+                    print(json.dumps(rec), flush=True)
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        dist.barrier()                    # rank 0 measured its roofline meanwhile
+        try:
+            tr = train_throughput(args.dtype, dev, dist=dist, rank=rank, world=world,
+                                  **({"steps": 2, "warmup": 1} if rehearsal else {}))   # gloo moves 480 MB through the host
+        except Exception as e:            # noqa: BLE001 -- reported in the line
+            tr = {"error": repr(e)}
+        done.set()
+        if rank == 0:
+            rec["train"] = tr
+    if rank == 0:
         print(json.dumps(rec), flush=True)
     if dist is not None:
         dist.barrier()
