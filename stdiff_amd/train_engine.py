@@ -269,7 +269,8 @@ class TrainEngine(TrainCore):
             self.world = dist.get_world_size(process_group)
             # RCCL ("nccl") collectives are stream-ordered: all buckets are issued asynchronously and overlap the rest
             # of the backward pass.  gloo (tests / single-GPU rehearsal) stalls with several asynchronous CUDA
-            # all-reduces in flight (observed: 8 x 12 MB), so there each bucket is reduced before the next is issued.
+            # all-reduces in flight (observed: 8 x 12 MB) or with one issued behind a busy stream, so there the device
+            # is synchronised and each bucket is reduced before the next is issued.
             self.async_buckets = dist.get_backend(process_group) == "nccl"
         self.buckets = self.bucket_ranges()
         self._graphs, self._stream = {}, None
@@ -305,6 +306,7 @@ class TrainEngine(TrainCore):
             if self.async_buckets:
                 handles.append(self.dist.all_reduce(self.flat_g[lo:hi], group=self.pg, async_op=True))
             else:
+                torch.cuda.synchronize(self.device)      # gloo + CUDA tensors behind a busy stream stalled on this stack
                 self.dist.all_reduce(self.flat_g[lo:hi], group=self.pg)
         self.backward(a, after_bucket=reduce_bucket if self.world > 1 else None)       # :77
         for h in handles:
