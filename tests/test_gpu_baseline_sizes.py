@@ -182,3 +182,37 @@ def test_config1_chunks_against_oracle_fp32():
             got = s.run([t], z=z.to(DEV)[None]).cpu()
             ref_x = ref_x * (1 - mk) + torch.from_numpy(gt[lo:hi]) * mk
             assert relerr(got, ref_x) < FP32_TOL, k
+
+
+# ---------------------------------------------------------------- configs[2] (per-rank shape of the DDP run)
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_config2_shape_training_iteration_against_oracle(dtype):
+    """configs[2]'s per-rank step: 512 cells x 2000 genes, hidden 2048 (16 heads -> d = 128), depth cut to 2 so that
+    the oracle's autograd finishes in seconds.  fp32: loss, gradient norm and every gradient against the oracle;
+    bf16: loss and gradient norm track the oracle (bf16 operands, fp32 accumulation)."""
+    from stdiff_amd.train_engine import TrainEngine
+    G, H, depth, heads, C, T = 2000, 2048, 2, 16, 512, 1000
+    m, p = build(G, H, depth, heads, 15, dtype)
+    mask, _ = problem(8, G)
+    st = (O.synth_expression(C, G, 3) * 2 - 1).astype(np.float32)
+    gen = torch.Generator().manual_seed(10)
+    noise = torch.randn(C, G, generator=gen)
+    tt = torch.randint(1, T, (C,), generator=gen)
+    x = torch.from_numpy(st)
+    xc = torch.from_numpy(st * mask * 1.0).float()
+    tb = O.make_tables(T, schedule="cosine")
+    loss_r, grads, _ = O.loss_and_grads(p, tb, x, xc, noise, tt, mask, heads, depth)
+    # float64: torch's CPU fp32 norm over tensors of 10^7..10^8 elements is itself only good to ~1e-3 here
+    gn_r = float(sum(g.double().pow(2).sum() for g in grads.values()) ** 0.5)
+    te = TrainEngine(m, lr=1e-4, diffusion_step=T, mask=mask)
+    loss, gn = te.step(x.to(DEV), xc.to(DEV), noise=noise.to(DEV), timesteps=tt.to(DEV))
+    print(f"configs[2] shape {dtype}: loss {float(loss):.6f} (oracle {float(loss_r):.6f}), |g| {float(gn):.5f} (oracle {gn_r:.5f})")
+    if dtype == "fp32":
+        assert abs(float(loss) - float(loss_r)) < 1e-5 * max(1.0, float(loss_r))
+        assert abs(float(gn) - gn_r) < 1e-4 * gn_r
+        gscale = max(float(g.abs().max()) for g in grads.values())
+        for n, g in grads.items():
+            assert float((te.g[n].cpu() - g).abs().max()) < 1e-4 * gscale, n
+    else:
+        assert abs(float(loss) - float(loss_r)) < 2e-2 * float(loss_r)
+        assert abs(float(gn) - gn_r) < 5e-2 * gn_r
