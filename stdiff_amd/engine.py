@@ -299,8 +299,15 @@ class LanedSampler:
         self.x = torch.empty((R, engine.pw.G), device=engine.pw.device, dtype=torch.float32)
         self.parts = []
         per, extra, c0, r0 = len(chunk_lens) // lanes, len(chunk_lens) % lanes, 0, 0
+        counts = [per + (1 if i < extra else 0) for i in range(lanes)]
+        split = os.environ.get("STDIFF_LANE_SPLIT")          # experiments: chunks per lane, e.g. "16,16,8"
+        if split:
+            counts = [int(v) for v in split.split(",")]
+            if sum(counts) != len(chunk_lens) or min(counts) < 1:
+                raise ValueError(f"STDIFF_LANE_SPLIT={split!r} does not partition {len(chunk_lens)} chunks")
+            lanes = len(counts)
         for i in range(lanes):
-            n = per + (1 if i < extra else 0)
+            n = counts[i]
             lens = chunk_lens[c0:c0 + n]
             r1 = r0 + sum(lens)
             self.parts.append(ReverseSampler(engine, sched, lens, x_cond[r0:r1], gt[r0:r1], mask, pred_type=pred_type,
