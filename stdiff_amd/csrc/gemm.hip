@@ -57,6 +57,9 @@ struct Params {
     int k_valid;         // K-major operands: rows k >= k_valid are zero (K itself is padded to the slab size)
     int ksplit, nk_per;  // split-K (128 x 128 kernel): grid = tiles * ksplit, split s covers K-slabs [s*nk_per, ..)
     float* ws; int ldws; // partial products [ksplit][M][ldws] fp32
+    // gemm256q work units: units [0, t_full) are whole 256 x 256 tiles; unit t_full + 2j + h is the 128-row half h of
+    // tile t_full + j (the tiles of a short last round are cut in two so that the round costs about half)
+    int t_full, units;
 };
 
 __device__ __forceinline__ void tile_of(int bid, int nblk, int tiles_m, int tiles_n, int& tm, int& tn) {
@@ -489,7 +492,7 @@ __device__ __forceinline__ f32x4 lds_read16(unsigned addr) {
 // next quarter.  Fully unrolled so that the two register sets are static.
 template <bool CBF>
 __device__ __forceinline__ void epi_tile256_gate_res(const Params& p, const f32x4 (&acc)[2][2][4][2], unsigned cla,
-                                                     int wid, int lane, int m0, int n0) {
+                                                     int wid, int lane, int m0, int n0, int nq) {
     asm volatile("" : "+v"(lane));       // per-lane offsets are recomputed per tile, not kept live across the K loop
     const int wr = wid >> 2, wc = wid & 3, fr = lane & 15, fq = lane >> 4;
     const int gn = n0 + lane * 4;
@@ -514,6 +517,7 @@ __device__ __forceinline__ void epi_tile256_gate_res(const Params& p, const f32x
     issue(0, 0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
+        if (q >= nq) break;                              // half unit: two quarters
         if (q) STDIFF_BARRIER();                         // image reads of the previous quarter are done
         const int mh = q >> 1, mp = q & 1;
 #pragma unroll
@@ -792,10 +796,13 @@ __global__ __launch_bounds__(512, 1) void gemm256q_kernel(Params p) {
     const unsigned voffA = (unsigned)((16 * wid + (lane >> 3)) * p.lda + swl) * 2u;
     const unsigned voffW = (unsigned)((16 * wid + (lane >> 3)) * p.ldw + swl) * 2u;
     unsigned sA = 0, sW = 0;       // byte offset of the tile's first row
-    auto set_tile = [&](int tile, int& m0, int& n0) {
-        int tm, tn;
+    bool full = true;              // the unit whose operands are in flight is a whole tile (else: rows m0 .. m0+127)
+    auto set_tile = [&](int unit, int& m0, int& n0) {
+        int tm, tn, tile = unit, mh = 0;
+        full = unit < p.t_full;
+        if (!full) { tile = p.t_full + ((unit - p.t_full) >> 1); mh = (unit - p.t_full) & 1; }
         tile_of(tile, ntiles, p.tiles_m, p.tiles_n, tm, tn);
-        m0 = tm * 256; n0 = tn * 256;
+        m0 = tm * 256 + mh * 128; n0 = tn * 256;
         sA = (unsigned)m0 * (unsigned)p.lda * 2u;
         sW = (unsigned)n0 * (unsigned)p.ldw * 2u;
     };
@@ -908,29 +915,32 @@ __global__ __launch_bounds__(512, 1) void gemm256q_kernel(Params p) {
             STDIFF_MMA(0, 0);
             STDIFF_MMA(0, 1);
             STDIFF_BARRIER();
-            // ---- P2: A1 x (B0, B1)
-            loadA(b, 1);
+            // ---- P2: A1 x (B0, B1); a half unit keeps the DMA schedule (its A1 rows are loaded and ignored)
+            if (full) loadA(b, 1);
             if (n2) { dma(b, 0, t + 2); dma(b, 2, t + 2); dma(b, 3, t + 2); STDIFF_VMCNT(8); }   // retire A0,B0,B1(t+1)
             else if (n1) { STDIFF_VMCNT(2); }
             STDIFF_BARRIER();
-            STDIFF_MMA(1, 0);
-            STDIFF_MMA(1, 1);
+            if (full) {
+                STDIFF_MMA(1, 0);
+                STDIFF_MMA(1, 1);
+            }
             STDIFF_BARRIER();
         }
         if (wr == 0) STDIFF_BARRIER();                 // balance the stagger: every wave is past its last LDS read
         STDIFF_STAMP(2);
 
         const int em0 = m0, en0 = n0, next = tile + (int)gridDim.x;
-        if (next < ntiles) {                           // next tile's operands fly in under the epilogue
+        const int nq = full ? 4 : 2;                   // quarters of this unit (a half unit holds rows in acc[0] only)
+        if (next < p.units) {                           // next tile's operands fly in under the epilogue
             set_tile(next, m0, n0);
             prologue();
         }
         if (p.vec && p.epi == STDIFF_EPI_GATE_RES && !p.C2) {
-            if (p.c_bf16) epi_tile256_gate_res<true>(p, acc, cla, wid, lane, em0, en0);
-            else epi_tile256_gate_res<false>(p, acc, cla, wid, lane, em0, en0);
+            if (p.c_bf16) epi_tile256_gate_res<true>(p, acc, cla, wid, lane, em0, en0, nq);
+            else epi_tile256_gate_res<false>(p, acc, cla, wid, lane, em0, en0, nq);
         } else
 #pragma unroll 1
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < nq; ++q) {
             if (q) STDIFF_BARRIER();                   // image reads of the previous quarter are done
             switch (q) {
                 case 0: put(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); break;
@@ -966,7 +976,7 @@ __global__ __launch_bounds__(512, 1) void gemm256q_kernel(Params p) {
         }
         STDIFF_STAMP(3);
         ++iter;
-        if (next >= ntiles) break;
+        if (next >= p.units) break;
         tile = next;
     }
 }
@@ -1082,9 +1092,21 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
         }
     }
     dim3 grid(p.tiles_m * p.tiles_n * p.ksplit), block(tile == 1 ? NT : 512);
+    p.t_full = p.units = p.tiles_m * p.tiles_n;
     if (tile == 3) {                                           // persistent: one workgroup per CU walks the tiles
         int cus = cu_count();
         if (const char* e = getenv("STDIFF_GEMM_CUS")) { const int v = atoi(e); if (v > 0 && v < cus) cus = v; }
+        // STDIFF_GEMM_SPLIT_TAIL=1 (opt-in): a last round that fills at most half of the CUs is cut into 128-row half
+        // units (two-phase kernel only).  Measured: one stream gains 2.6 % over the 33 launches (fc2 222 -> 209 us), but
+        // with two concurrent lanes the step is 2.3 % SLOWER -- the CUs a short round leaves free are exactly where the
+        // other lane's kernels run -- so the default stays off.
+        const int T = p.units, frac = T % cus;
+        const char* se = getenv("STDIFF_GEMM_SPLIT_TAIL");
+        if (variant_q && frac > 0 && 2 * frac <= cus && se && atoi(se) == 1) {
+            p.t_full = T - frac;
+            p.units = p.t_full + 2 * frac;
+            grid.x = p.units;
+        }
         grid.x = min((int)grid.x, cus);
     }
 #define STDIFF_LAUNCH128(T)                                                                                    \

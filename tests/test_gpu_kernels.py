@@ -153,13 +153,16 @@ def test_gemm_k_major_operands(ops, L, dt, M, N, K):
     assert relerr(sub, ref[:sub.shape[0]]) < tol                      # a row subset of a wider K-major operand
 
 
-@pytest.mark.parametrize("variant", ["3", "4"])
+@pytest.mark.parametrize("variant", ["3", "4", "4s"])
 @pytest.mark.parametrize("M,N,K", [(600, 520, 256), (257, 264, 64), (1024, 512, 1024), (300, 1000, 192)])
 def test_gemm_256_kernel_all_epilogues(ops, L, M, N, K, variant, monkeypatch):
     """The persistent 256 x 256 bf16 kernel forced (STDIFF_GEMM_TILE=3 is read per call): ragged M / N edges, every
     epilogue kind, fp32 and bf16 outputs, K of 1 / 3 / 4 / 16 slabs (prologue and tail of the refill schedule).  Variant 3 =
-    four 16-MFMA phases per slab, 4 = two 32-MFMA phases (the default)."""
-    monkeypatch.setenv("STDIFF_GEMM_TILE", variant)
+    four 16-MFMA phases per slab, 4 = two 32-MFMA phases (the default), 4s = the same with the tiles of a short last
+    round cut into 128-row half units (STDIFF_GEMM_SPLIT_TAIL=1; here every tile is in that round)."""
+    monkeypatch.setenv("STDIFF_GEMM_TILE", variant[0])
+    if variant.endswith("s"):
+        monkeypatch.setenv("STDIFF_GEMM_SPLIT_TAIL", "1")
     dt = "bf16"
     A, W, b = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=K ** -0.5), rnd(N, seed=13, scale=0.1)
     v = q(A, dt) @ q(W, dt).T + b
