@@ -52,7 +52,8 @@ struct Params {
     const void* gate; int ldgate;
     const float* res; int ldres;
     void* C2; int ldc2;
-    int vec;  // every epilogue pointer / stride allows aligned 4-wide (16 B fp32, 8 B bf16) access and N % 8 == 0
+    int vec;  // != 0: every epilogue pointer / stride allows aligned 4-wide (16 B fp32, 8 B bf16) access and N % 8 == 0;
+              // 2: a bf16 C additionally allows 16-byte row pieces
     int tiles_m, tiles_n;
     int k_valid;         // K-major operands: rows k >= k_valid are zero (K itself is padded to the slab size)
     int ksplit, nk_per;  // split-K (128 x 128 kernel): grid = tiles * ksplit, split s covers K-slabs [s*nk_per, ..)
@@ -569,6 +570,59 @@ __device__ __forceinline__ void epi_tile256_gate_res(const Params& p, const f32x
     }
 }
 
+// Whole-tile epilogue of the two-phase kernel for bf16 outputs without side inputs (bias / SiLU / GELU: adaLN, qkv,
+// fc1, the final adaLN): the epilogue arithmetic runs on the accumulator registers, the RESULT is staged as bf16 --
+// one 128-row x 256-column image (64 KiB) per M half, so a tile takes 2 put/barrier/copy rounds instead of 4 and moves
+// half the LDS bytes of the fp32 quarter images -- and leaves as 16-byte stores, 32 lanes to a 512-byte row.
+// Image: row r (512 B) holds 64 8-byte chunks; chunk c of row r sits at c ^ ((r & 7) << 2) ^ (((r >> 3) & 1) << 1):
+// the 32 lanes of a half wave (16 rows x 2 neighbouring chunks) then write 32 distinct bank pairs, and a 16-byte
+// read unit (chunks 2p, 2p + 1) stays adjacent because bit 0 is never flipped.
+template <int EPI>
+__device__ __forceinline__ void epi_tile256_bf16(const Params& p, const f32x4 (&acc)[2][2][4][2], unsigned char* img,
+                                                 int tid, int wid, int lane, int m0, int n0, int nq) {
+    asm volatile("" : "+v"(lane), "+v"(tid));   // per-lane offsets are recomputed per tile, not kept live across the K loop
+    const int wr = wid >> 2, wc = wid & 3, fr = lane & 15, fq = lane >> 4;
+    f32x4 b4[2][2];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int gn = n0 + nh * 128 + wc * 32 + nt * 16 + fq * 4;
+            b4[nh][nt] = (p.bias && gn < p.N) ? *(const f32x4*)(p.bias + gn) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    const int sw = ((fr & 7) << 2) ^ ((fr >> 3) << 1);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+        if (2 * mh >= nq) break;                         // half unit: rows of acc[0] only
+        if (mh) STDIFF_BARRIER();                        // image reads of the first half are done
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const f32x4 o = epi_math<EPI, true>(acc[mh][nh][mt][nt] + b4[nh][nt], zero, zero);
+                    u32x2 rr;
+                    rr[0] = pack2bf(o[0], o[1]);
+                    rr[1] = pack2bf(o[2], o[3]);
+                    const int r = wr * 64 + mt * 16 + fr, c = nh * 32 + wc * 8 + nt * 4 + fq;
+                    *(u32x2*)(img + r * 512 + ((c ^ sw) << 3)) = rr;
+                }
+        STDIFF_LGKMCNT0();
+        STDIFF_BARRIER();
+        const int pair = tid & 31, gn = n0 + pair * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int row = (tid >> 5) + 16 * k, gm = m0 + mh * 128 + row;
+            const int rs = ((row & 7) << 2) ^ (((row >> 3) & 1) << 1);
+            const u32x4 v = *(const u32x4*)(img + row * 512 + (((2 * pair) ^ rs) << 3));
+            if (gm < p.M && gn < p.N) __builtin_nontemporal_store(v, (u32x4*)((bf16_t*)p.C + (size_t)gm * p.ldc + gn));
+        }
+        STDIFF_LGKMCNT0();
+    }
+}
+
 // PERSISTENT: the grid is min(tiles, CUs) workgroups and each walks tiles b, b + grid, ...  The LDS holds 9 half-tile
 // slots (144 KiB): [buf0: A0 A1 B0 B1][buf1: A0 A1 B0 B1][extra]; the epilogue's fp32 C image (64 rows at a time) lives
 // in the LAST FOUR slots, so the next tile's prologue (slab 0 into buf0 and A0 of slab 1 into buf1.A0) is issued by
@@ -935,7 +989,12 @@ __global__ __launch_bounds__(512, 1) void gemm256q_kernel(Params p) {
             set_tile(next, m0, n0);
             prologue();
         }
-        if (p.vec && p.epi == STDIFF_EPI_GATE_RES && !p.C2) {
+        if (p.vec == 2 && p.c_bf16 && !p.C2 && p.epi <= STDIFF_EPI_GELU) {     // bias / SiLU / GELU, 16-byte C rows
+            unsigned char* img = smem + 5 * HALF;
+            if (p.epi == STDIFF_EPI_GELU) epi_tile256_bf16<STDIFF_EPI_GELU>(p, acc, img, tid, wid, lane, em0, en0, nq);
+            else if (p.epi == STDIFF_EPI_SILU) epi_tile256_bf16<STDIFF_EPI_SILU>(p, acc, img, tid, wid, lane, em0, en0, nq);
+            else epi_tile256_bf16<STDIFF_EPI_BIAS>(p, acc, img, tid, wid, lane, em0, en0, nq);
+        } else if (p.vec && p.epi == STDIFF_EPI_GATE_RES && !p.C2) {
             if (p.c_bf16) epi_tile256_gate_res<true>(p, acc, cla, wid, lane, em0, en0, nq);
             else epi_tile256_gate_res<false>(p, acc, cla, wid, lane, em0, en0, nq);
         } else
@@ -1050,7 +1109,7 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
         vec = vec && a->ldgate % 4 == 0 && (bf ? al8(a->gate) : al16(a->gate)) && al16(a->res) && a->ldres % 4 == 0;
     if (a->epi == STDIFF_EPI_ADD) vec = vec && al16(a->res) && a->ldres % 4 == 0;
     if (a->C2) vec = vec && a->ldc2 % 4 == 0 && (bf ? al8(a->C2) : al16(a->C2));
-    p.vec = vec;
+    p.vec = vec ? ((p.c_bf16 && a->ldc % 8 == 0 && al16(a->C)) ? 2 : 1) : 0;   // 2: bf16 C rows allow 16-byte stores
 
     // tile choice (bf16): the 256 x 256 pipelined kernel (1 block/CU) when its grid keeps the chip busy
     const char* fenv = getenv("STDIFF_GEMM_TILE");      // 1 / 3 force a kernel (tests, A/B timing)
