@@ -25,6 +25,9 @@
 namespace {
 
 constexpr int BQ = 128, BKV = 64;
+#ifndef ATTN_FWD_OCC
+#define ATTN_FWD_OCC 2
+#endif
 
 template <typename T, int D> struct ACfg;
 template <int D> struct ACfg<bf16_t, D> {
@@ -123,6 +126,37 @@ __device__ __forceinline__ void tr_accumulate(f32x16 (&o)[D / 32], const unsigne
     }
 }
 
+// bf16 only: the two halves of tr_accumulate, so that the V^T fragments of a key tile can be requested BEFORE the
+// softmax arithmetic (they do not depend on it) and land under it instead of in front of every MFMA.
+template <int D>
+__device__ __forceinline__ void tr_fragments(bf16x8 (&a)[D / 32][2], const unsigned char* img, int sub, int lane) {
+    using C = ACfg<bf16_t, D>;
+    const int hh = lane >> 5, g1 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
+#pragma unroll
+    for (int b = 0; b < D / 32; ++b)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int kb = sub * 32 + 16 * ks + 4 * hh + q4;
+            const unsigned char* va = img + kb * C::TSTR + (b * 32 + 16 * g1 + 4 * p4) * 2;
+            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(va));
+            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                (__attribute__((address_space(3))) bf16x4*)(va + 8 * C::TSTR));
+            a[b][ks] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+}
+template <int D>
+__device__ __forceinline__ void tr_mma(f32x16 (&o)[D / 32], const bf16x8 (&a)[D / 32][2], const f32x16& x) {
+    bf16x8 xb[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xb[ks][e] = (__bf16)x[8 * ks + e];
+#pragma unroll
+    for (int b = 0; b < D / 32; ++b)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) o[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[b][ks], xb[ks], o[b], 0, 0, 0);
+}
+
 // cooperative staging of a [64][D] tile (rows r0+k0.., clamped to the chunk) into a row image and/or a tr image
 template <typename T, int D> struct TileStage {
     using C = ACfg<T, D>;
@@ -159,7 +193,7 @@ __device__ __forceinline__ void store_rows(T* dst, const f32x16 (&o)[D / 32], fl
 
 // ================================================================ forward
 template <typename T, int D>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ qkv, int ldqkv, T* __restrict__ out,
+__global__ __launch_bounds__(256, ATTN_FWD_OCC) void attn_fwd_kernel(const T* __restrict__ qkv, int ldqkv, T* __restrict__ out,
                                                        int ldo, float* __restrict__ lse,
                                                        const int32_t* __restrict__ cu_rows, int heads, float c_log2) {
     using C = ACfg<T, D>;
@@ -207,6 +241,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
         // a read-modify-write of all of them per tile).  exp2 is the bare v_exp_f32.
         constexpr float LAZY = 6.0f;
         const bool two = k0 + 32 < len;
+        constexpr bool PREV = BF && D <= 64;                         // registers allow it (d = 128: 226 VGPRs already)
+        bf16x8 vf[2][PREV ? D / 32 : 1][2];
+        if constexpr (PREV) {
+            tr_fragments<D>(vf[0], vls, 0, lane);
+            tr_fragments<D>(vf[1], vls, 1, lane);                    // a tile past the chunk: finite stale data x P = 0
+            __builtin_amdgcn_sched_barrier(0);
+        }
         f32x16 sa = rows_dot_regs<T, D>(kls, 0, qf, lane);           // S^T[key, q], raw scores
         f32x16 sb;
         if (two) sb = rows_dot_regs<T, D>(kls, 1, qf, lane);
@@ -243,8 +284,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const T* __restrict__ 
             ps += sa[r] + sb[r];
         }
         l_run += ps;
-        tr_accumulate<T, D>(o, vls, 0, sa, lane);                    // O^T[d, q] += V^T . P^T
-        if (two) tr_accumulate<T, D>(o, vls, 1, sb, lane);
+        if constexpr (PREV) {
+            tr_mma<D>(o, vf[0], sa);                                 // O^T[d, q] += V^T . P^T
+            if (two) tr_mma<D>(o, vf[1], sb);
+        } else {
+            tr_accumulate<T, D>(o, vls, 0, sa, lane);
+            if (two) tr_accumulate<T, D>(o, vls, 1, sb, lane);
+        }
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (qrow < len) {
