@@ -7,7 +7,7 @@ HBM.  Workload = BASELINE.json configs[1]: 20 000 spots x 1000 genes, hidden 102
 (the reference batch size), cosine schedule T=1000.   value = spots / (1000 * seconds-per-step), aggregate over ranks.
 Per-step cost does not depend on t, so K timed steps stand for the 1000-step run (stated in `config`).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp32] [--rows R]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp16|fp32] [--rows R]
 N>1: launched by torch.distributed.run, one rank per GPU; spots are sharded chunk-aligned over ranks with no
 collective in the loop (weak scaling: every rank holds --rows spots).
 """
@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 G, H, DEPTH, HEADS, BATCH, T = 1000, 1024, 6, 16, 512, 1000
-PEAK = {"bf16": 2500.0, "fp32": 157.3}     # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
+PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}     # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
 
 
 def build_model(dtype, device):
@@ -93,7 +93,7 @@ def measure_gemm_roofline(eng, ws, dtype, reps=3):
     tfile = os.path.join(ROOT, "profiles", "gemm_traffic.json")      # PMC-derived HBM bytes per launch, if collected
     if os.path.isfile(tfile):
         traffic = json.load(open(tfile)).get(dtype)
-    return {"bound": "mfma", "kernel": "gemm256q_kernel (+ gemm_nt_kernel<bf16> where its grid fits better)" if dtype == "bf16"
+    return {"bound": "mfma", "kernel": "gemm256q_kernel (+ gemm_nt_kernel<16-bit> where its grid fits better)" if dtype != "fp32"
             else "gemm_nt_kernel<float>", "achieved": round(achieved, 1),
             "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK[dtype], 4), "traffic": traffic,
             "launches_per_step": len(launches), "avg_launch_us": round(avg_ms * 1e3, 1),
@@ -106,7 +106,7 @@ def measure_hbm_kernels(eng, ws, sched, gt, mask, dtype, reps=10):
     from stdiff_amd import ops
     from stdiff_amd.engine import step_coefficients
     R, dev = ws.R, ws.h.device
-    s_el = 2 if dtype == "bf16" else 4
+    s_el = 4 if dtype == "fp32" else 2
     ycond = torch.randn(R, H, device=dev)
     temb = torch.randn(T, H, device=dev)
     t_dev = torch.full((1,), T // 2, device=dev, dtype=torch.int32)
@@ -216,7 +216,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--rows", type=int, default=20000, help="spots per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
@@ -250,6 +250,7 @@ def main():
     from stdiff_amd.model.stDiff_scheduler import NoiseScheduler
 
     model = build_model(args.dtype, dev)
+    train_dtype = "bf16" if args.dtype == "fp16" else args.dtype     # fp16 is a sampling format; training stays bf16
     eng = model.engine()
     R = args.rows
     lens = [min(BATCH, R - i) for i in range(0, R, BATCH)]
@@ -318,7 +319,7 @@ def main():
         if world == 1 and not args.no_train:
             del smp
             torch.cuda.empty_cache()
-            rec["train"] = train_throughput(args.dtype, dev)
+            rec["train"] = train_throughput(train_dtype, dev)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
     if world > 1 and not args.no_train:
@@ -336,7 +337,7 @@ def main():
         threading.Thread(target=watchdog, daemon=True).start()
         dist.barrier()                    # rank 0 measured its roofline meanwhile
         try:
-            tr = train_throughput(args.dtype, dev, dist=dist, rank=rank, world=world,
+            tr = train_throughput(train_dtype, dev, dist=dist, rank=rank, world=world,
                                   **({"steps": 2, "warmup": 1} if rehearsal else {}))   # gloo moves 480 MB through the host
         except Exception as e:            # noqa: BLE001 -- reported in the line
             tr = {"error": repr(e)}

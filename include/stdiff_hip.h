@@ -13,7 +13,10 @@
  *     no host synchronisation, so every entry point may be stream-captured into a hipGraph
  *     (stdiff_graph_*);
  *   - matrices are row-major with an explicit leading dimension in ELEMENTS;
- *   - dtype: STDIFF_F32 (exact-fp32 MFMA path) or STDIFF_BF16 (bf16 MFMA, fp32 accumulate).
+ *   - dtype: STDIFF_F32 (exact-fp32 MFMA path) or STDIFF_BF16 (16-bit MFMA operands, fp32 accumulate).  The
+ *     16-bit FORMAT is a property of the build: libstdiff_hip.so computes in bf16; libstdiff_hip_f16.so (same
+ *     sources, same entry points, -DSTDIFF_H16_FP16) in IEEE fp16 with saturating conversions, for sampling
+ *     (stdiff_h16_format() tells which one was loaded).
  */
 #ifndef STDIFF_HIP_H
 #define STDIFF_HIP_H
@@ -24,7 +27,7 @@
 extern "C" {
 #endif
 
-#define STDIFF_ABI_VERSION 3
+#define STDIFF_ABI_VERSION 4
 
 enum { STDIFF_F32 = 0, STDIFF_BF16 = 1 };
 
@@ -48,6 +51,8 @@ enum {
 };
 
 int stdiff_abi_version(void);
+/* 16-bit operand format of this build: 0 = bf16, 1 = IEEE fp16 (no counterpart in the reference, which is fp32). */
+int stdiff_h16_format(void);
 const char* stdiff_error_string(int status);
 
 /* ---------------------------------------------------------------- dense contractions (MFMA)

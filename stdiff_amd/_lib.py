@@ -1,15 +1,19 @@
-"""ctypes binding of libstdiff_hip.so (include/stdiff_hip.h).  Fails loudly if the library is missing:
-there is no CPU or eager-PyTorch fallback anywhere in this package."""
+"""ctypes binding of libstdiff_hip.so / libstdiff_hip_f16.so (include/stdiff_hip.h).  Fails loudly if a library
+is missing: there is no CPU or eager-PyTorch fallback anywhere in this package.
+
+The two libraries are the same sources built with bf16 resp. IEEE fp16 as the 16-bit MFMA operand format; at the
+C ABI both call it dtype code 1.  Python keeps them apart by the torch dtype of the tensors (``lib_for``)."""
 import ctypes as C
 import os
 
 import torch
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2         # F16 exists on the Python side only: it selects the fp16 build, whose C code is 1
 EPI_BIAS, EPI_SILU, EPI_GELU, EPI_GATE_RES, EPI_ADD, EPI_GELU_SAVE, EPI_ACCUM = range(7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstdiff_hip.so")
+LIB_PATH_F16 = os.path.join(_HERE, "libstdiff_hip_f16.so")
 
 vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
 
@@ -61,6 +65,7 @@ class AdamWArgs(C.Structure):
 
 _SIGS = {
     "stdiff_abi_version": (i32, []),
+    "stdiff_h16_format": (i32, []),
     "stdiff_error_string": (C.c_char_p, [i32]),
     "stdiff_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "stdiff_transpose": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
@@ -94,28 +99,44 @@ _SIGS = {
     "stdiff_graph_destroy": (i32, [vp]),
 }
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    """The loaded library (raises if it was not built: run `python -c 'import __graft_entry__ as g; g.build()'`)."""
-    global _lib
-    if _lib is None:
-        if not os.path.isfile(LIB_PATH):
+def lib(fp16=False):
+    """The loaded library (raises if it was not built: run `python -c 'import __graft_entry__ as g; g.build()'`).
+    fp16=True: the build whose 16-bit operand format is IEEE fp16."""
+    L = _libs.get(bool(fp16))
+    if L is None:
+        path = LIB_PATH_F16 if fp16 else LIB_PATH
+        base = os.path.basename(path)
+        if not os.path.isfile(path):
             raise RuntimeError(
-                f"{LIB_PATH} is missing: the HIP extension was not built (make -C stdiff_amd/csrc). "
+                f"{path} is missing: the HIP extension was not built (make -C stdiff_amd/csrc). "
                 "stdiff_amd has no CPU fallback.")
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         missing = [name for name in _SIGS if not hasattr(L, name)]
         if missing:
-            raise RuntimeError(f"libstdiff_hip.so lacks symbols declared in include/stdiff_hip.h: {missing}")
+            raise RuntimeError(f"{base} lacks symbols declared in include/stdiff_hip.h: {missing}")
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.stdiff_abi_version() != 3:
-            raise RuntimeError("libstdiff_hip.so ABI version mismatch")
-        _lib = L
-    return _lib
+        if L.stdiff_abi_version() != 4:
+            raise RuntimeError(f"{base} ABI version mismatch")
+        if L.stdiff_h16_format() != int(bool(fp16)):
+            raise RuntimeError(f"{base} was built with the wrong 16-bit operand format")
+        _libs[bool(fp16)] = L
+    return L
+
+
+def lib_for(*tensors):
+    """The library that computes in the 16-bit format of these tensors: the fp16 build if any of them is
+    torch.float16 (mixing it with bfloat16 is an error), else the default (bf16 / fp32) build."""
+    kinds = {t.dtype for t in tensors if isinstance(t, torch.Tensor)}
+    if torch.float16 in kinds:
+        if torch.bfloat16 in kinds:
+            raise TypeError("float16 and bfloat16 tensors in one stdiff_hip call")
+        return lib(True)
+    return lib()
 
 
 class StdiffError(RuntimeError):
@@ -142,13 +163,18 @@ def stream():
 def dt_of(t):
     if t.dtype == torch.float32:
         return F32
-    if t.dtype == torch.bfloat16:
+    if t.dtype in (torch.bfloat16, torch.float16):     # the C ABI's "16-bit operand" code; lib_for() picks the build
         return BF16
     raise TypeError(f"unsupported dtype {t.dtype}")
 
 
 def torch_dtype(dt):
-    return torch.bfloat16 if dt == BF16 else torch.float32
+    return {F32: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[dt]
+
+
+def c_dtype(dt):
+    """Python compute-dtype code -> the C ABI's dtype code."""
+    return F32 if dt == F32 else BF16
 
 
 def require_gpu(*tensors):

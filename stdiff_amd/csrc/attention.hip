@@ -75,7 +75,7 @@ __device__ __forceinline__ f32x16 rows_dot_regs(const unsigned char* img, int su
 #pragma unroll
         for (int ss = 0; ss < D / 16; ++ss) {
             bf16x8 a = *(const bf16x8*)(row + (16 * ss + 8 * hh) * 2);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, f.v[ss], s, 0, 0, 0);
+            s = STDIFF_MFMA_32x32x16_H16(a, f.v[ss], s, 0, 0, 0);
         }
     } else {
 #pragma unroll
@@ -99,7 +99,7 @@ __device__ __forceinline__ void tr_accumulate(f32x16 (&o)[D / 32], const unsigne
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) xb[ks][e] = (__bf16)x[8 * ks + e];
+            for (int e = 0; e < 8; ++e) xb[ks][e] = (h16)x[8 * ks + e];
         const int g1 = (lane >> 4) & 1, q4 = (lane & 15) >> 2, p4 = lane & 3;
 #pragma unroll
         for (int b = 0; b < D / 32; ++b) {
@@ -107,11 +107,10 @@ __device__ __forceinline__ void tr_accumulate(f32x16 (&o)[D / 32], const unsigne
             for (int ks = 0; ks < 2; ++ks) {
                 const int kb = sub * 32 + 16 * ks + 4 * hh + q4;
                 const unsigned char* va = img + kb * C::TSTR + (b * 32 + 16 * g1 + 4 * p4) * 2;
-                bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(va));
-                bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (__attribute__((address_space(3))) bf16x4*)(va + 8 * C::TSTR));
+                bf16x4 lo = ds_read_tr16_b64(va);
+                bf16x4 hi = ds_read_tr16_b64(va + 8 * C::TSTR);
                 bf16x8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                o[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xb[ks], o[b], 0, 0, 0);
+                o[b] = STDIFF_MFMA_32x32x16_H16(a, xb[ks], o[b], 0, 0, 0);
             }
         }
     } else {
@@ -138,9 +137,8 @@ __device__ __forceinline__ void tr_fragments(bf16x8 (&a)[D / 32][2], const unsig
         for (int ks = 0; ks < 2; ++ks) {
             const int kb = sub * 32 + 16 * ks + 4 * hh + q4;
             const unsigned char* va = img + kb * C::TSTR + (b * 32 + 16 * g1 + 4 * p4) * 2;
-            bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(va));
-            bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                (__attribute__((address_space(3))) bf16x4*)(va + 8 * C::TSTR));
+            bf16x4 lo = ds_read_tr16_b64(va);
+            bf16x4 hi = ds_read_tr16_b64(va + 8 * C::TSTR);
             a[b][ks] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
 }
@@ -150,11 +148,11 @@ __device__ __forceinline__ void tr_mma(f32x16 (&o)[D / 32], const bf16x8 (&a)[D 
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) xb[ks][e] = (__bf16)x[8 * ks + e];
+        for (int e = 0; e < 8; ++e) xb[ks][e] = (h16)x[8 * ks + e];
 #pragma unroll
     for (int b = 0; b < D / 32; ++b)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) o[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[b][ks], xb[ks], o[b], 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) o[b] = STDIFF_MFMA_32x32x16_H16(a[b][ks], xb[ks], o[b], 0, 0, 0);
 }
 
 // cooperative staging of a [64][D] tile (rows r0+k0.., clamped to the chunk) into a row image and/or a tr image

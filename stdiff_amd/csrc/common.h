@@ -5,9 +5,31 @@
 
 #include "../../include/stdiff_hip.h"
 
-typedef unsigned short bf16_t;  // storage type of a bf16 element
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+// The 16-bit operand format is a property of the BUILD: libstdiff_hip.so computes in bf16 (8-bit mantissa, fp32
+// range), libstdiff_hip_f16.so (-DSTDIFF_H16_FP16, sampling only) in IEEE fp16 (11-bit mantissa: per-call error of the
+// denoiser 8x smaller at the same MFMA rate; conversions saturate at +-65504).  Both are dtype code STDIFF_BF16 (= "the
+// library's 16-bit format") at the C ABI; `bf16_t` / `bf16x8` below name the 16-bit storage and MFMA fragment types of
+// either build.
+#ifdef STDIFF_H16_FP16
+typedef _Float16 h16;
+#define STDIFF_MFMA_16x16x32_H16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define STDIFF_MFMA_32x32x16_H16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+typedef __fp16 tr16_raw __attribute__((__vector_size__(4 * sizeof(__fp16))));
+#define STDIFF_TR16_BUILTIN __builtin_amdgcn_ds_read_tr16_b64_v4f16
+#else
+typedef __bf16 h16;
+#define STDIFF_MFMA_16x16x32_H16 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define STDIFF_MFMA_32x32x16_H16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+typedef __bf16 tr16_raw __attribute__((__vector_size__(4 * sizeof(__bf16))));
+#define STDIFF_TR16_BUILTIN __builtin_amdgcn_ds_read_tr16_b64_v4bf16
+#endif
+typedef unsigned short bf16_t;  // storage type of a 16-bit element
+typedef __attribute__((ext_vector_type(8))) h16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) h16 bf16x4;
+// ds_read_b64_tr_b16: the hardware transposes a 4-row x 16-column block of 16-bit elements per 16 lanes
+__device__ __forceinline__ bf16x4 ds_read_tr16_b64(const void* lds_ptr) {
+    return __builtin_bit_cast(bf16x4, STDIFF_TR16_BUILTIN((__attribute__((address_space(3))) tr16_raw*)lds_ptr));
+}
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -26,16 +48,29 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
         if (e__ != hipSuccess) return (int)e__; \
     } while (0)
 
+typedef float f32x2_cv __attribute__((ext_vector_type(2)));
+typedef h16 bf16x2_cv __attribute__((ext_vector_type(2)));
+#ifdef STDIFF_H16_FP16
+__device__ __forceinline__ float h16_sat(float f) { return __builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f); }
+__device__ __forceinline__ float bf2f(bf16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (_Float16)h16_sat(f)); }  // RNE
+__device__ __forceinline__ float bf_lo(unsigned u) { return bf2f((bf16_t)(u & 0xffffu)); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return bf2f((bf16_t)(u >> 16)); }
+__device__ __forceinline__ unsigned pack2bf(float a, float b) {
+    f32x2_cv v = {h16_sat(a), h16_sat(b)};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_cv));
+}
+#else
 __device__ __forceinline__ float bf2f(bf16_t u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }  // RNE, NaN-safe
-
+__device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 // two floats -> packed bf16 pair (RNE), one v_cvt_pk_bf16_f32
-typedef float f32x2_cv __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2_cv __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack2bf(float a, float b) {
     f32x2_cv v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_cv));
 }
+#endif
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -52,10 +87,10 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *(const f32x4*)p; 
 __device__ __forceinline__ f32x4 ld4(const bf16_t* p) {
     u32x2 r = *(const u32x2*)p;
     f32x4 v;
-    v[0] = __builtin_bit_cast(float, r[0] << 16);
-    v[1] = __builtin_bit_cast(float, r[0] & 0xffff0000u);
-    v[2] = __builtin_bit_cast(float, r[1] << 16);
-    v[3] = __builtin_bit_cast(float, r[1] & 0xffff0000u);
+    v[0] = bf_lo(r[0]);
+    v[1] = bf_hi(r[0]);
+    v[2] = bf_lo(r[1]);
+    v[3] = bf_hi(r[1]);
     return v;
 }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *(f32x4*)p = v; }

@@ -4,6 +4,14 @@
 
 extern "C" int stdiff_abi_version(void) { return STDIFF_ABI_VERSION; }
 
+extern "C" int stdiff_h16_format(void) {
+#ifdef STDIFF_H16_FP16
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" const char* stdiff_error_string(int s) {
     switch (s) {
         case STDIFF_OK: return "ok";

@@ -293,16 +293,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
                     const int kb = ks * 32 + 8 * fq + (fr >> 2), fk = (kb & 3) | (((kb >> 3) & 1) << 2);
                     if constexpr (AK) {
                         const unsigned char* a0 = ba + kb * 256 + ((((wm * 64 + t * 16) >> 4) ^ fk) << 5) + 8 * (fr & 3);
-                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)a0);
-                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(a0 + 4 * 256));
+                        bf16x4 lo = ds_read_tr16_b64(a0);
+                        bf16x4 hi = ds_read_tr16_b64(a0 + 4 * 256);
                         af[t] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     } else {
                         af[t] = *(const bf16x8*)(ba + ra_ * ROWB + ((slot ^ C::swz(ra_)) << 4));
                     }
                     if constexpr (WK) {
                         const unsigned char* w0 = bw + kb * 256 + ((((wn * 64 + t * 16) >> 4) ^ fk) << 5) + 8 * (fr & 3);
-                        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)w0);
-                        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(w0 + 4 * 256));
+                        bf16x4 lo = ds_read_tr16_b64(w0);
+                        bf16x4 hi = ds_read_tr16_b64(w0 + 4 * 256);
                         wf[t] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     } else {
                         wf[t] = *(const bf16x8*)(bw + rw_ * ROWB + ((slot ^ C::swz(rw_)) << 4));
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = STDIFF_MFMA_16x16x32_H16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
             }
         } else {
             f32x4 af[4], wf[4];
@@ -547,10 +547,10 @@ __device__ __forceinline__ void epi_tile256_gate_res(const Params& p, const f32x
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
                 f32x4 g;
-                g[0] = __builtin_bit_cast(float, graw[slot][ps][0] << 16);
-                g[1] = __builtin_bit_cast(float, graw[slot][ps][0] & 0xffff0000u);
-                g[2] = __builtin_bit_cast(float, graw[slot][ps][1] << 16);
-                g[3] = __builtin_bit_cast(float, graw[slot][ps][1] & 0xffff0000u);
+                g[0] = bf_lo(graw[slot][ps][0]);
+                g[1] = bf_hi(graw[slot][ps][0]);
+                g[2] = bf_lo(graw[slot][ps][1]);
+                g[3] = bf_hi(graw[slot][ps][1]);
                 v[ps] = r[slot][ps] + g * (v[ps] + bias4);
                 asm volatile("" : "+v"(v[ps]));          // keep the math out of the predicated blocks
             }
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(Params p) {
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                      \
         _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                      \
             acc[MH][NH][mt][nt] =                                                                             \
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt][ks], af[mt][ks], acc[MH][NH][mt][nt], 0, 0, 0); \
+                STDIFF_MFMA_16x16x32_H16(bfr[nt][ks], af[mt][ks], acc[MH][NH][mt][nt], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                        \
     } while (0)
 
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(512, 1) void gemm256q_kernel(Params p) {
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                      \
         _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                      \
             acc[MH][NH][mt][nt] =                                                                             \
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[NH][nt][ks], af[mt][ks], acc[MH][NH][mt][nt], 0, 0, 0); \
+                STDIFF_MFMA_16x16x32_H16(bfr[NH][nt][ks], af[mt][ks], acc[MH][NH][mt][nt], 0, 0, 0); \
         __builtin_amdgcn_s_setprio(0);                                                                        \
     } while (0)
 

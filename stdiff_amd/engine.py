@@ -11,9 +11,10 @@ import torch
 
 from . import _lib as L
 from . import ops
-from ._lib import BF16, F32, check, lib, ptr, stream, torch_dtype
+from ._lib import BF16, F16, F32, c_dtype, check, lib_for, ptr, stream, torch_dtype
 
-DTYPES = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}
+DTYPES = {"fp32": F32, "f32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16,
+          "fp16": F16, "f16": F16, "float16": F16, "half": F16}
 
 
 def parse_dtype(name):
@@ -22,7 +23,7 @@ def parse_dtype(name):
     try:
         return DTYPES[str(name).lower()]
     except KeyError:
-        raise ValueError(f"compute dtype must be 'fp32' or 'bf16', got {name!r}")
+        raise ValueError(f"compute dtype must be 'fp32', 'bf16' or 'fp16' (sampling only), got {name!r}")
 
 
 def sinusoid_freqs(device):
@@ -83,7 +84,7 @@ class PackedWeights:
                 setattr(bw, f + "_w", ptr(self.w[pre + n + ".weight"]))
                 setattr(bw, f + "_b", ptr(self.b(pre + n + ".bias")))
         s = L.DitWeights()
-        s.dtype, s.G, s.Gp, s.H, s.heads, s.depth = self.dtype, self.G, self.Gp, self.H, self.heads, self.depth
+        s.dtype, s.G, s.Gp, s.H, s.heads, s.depth = c_dtype(self.dtype), self.G, self.Gp, self.H, self.heads, self.depth
         s.in_w, s.in_b = ptr(self.w["in_layer.0.weight"]), ptr(self.b("in_layer.0.bias"))
         s.out_w, s.out_b = ptr(self.w["out_layer.linear.weight"]), ptr(self.b("out_layer.linear.bias"))
         s.fada_w = ptr(self.w["out_layer.adaLN_modulation.1.weight"])
@@ -151,7 +152,7 @@ class DenoiserEngine:
 
     def run(self, ws):
         """eps = blocks/final(in_layer(ws.xp); ws.s)   (stDiff_model.py:240-243)."""
-        check(lib().stdiff_dit_forward(C.byref(self.pw.struct), C.byref(ws.struct), ptr(ws.xp), ptr(ws.s),
+        check(lib_for(ws.xp).stdiff_dit_forward(C.byref(self.pw.struct), C.byref(ws.struct), ptr(ws.xp), ptr(ws.s),
                                        ptr(ws.eps), ws.eps.stride(0), stream()))
         return ws.eps
 

@@ -77,8 +77,9 @@ class DiT_stDiff(nn.Module):
     ACROSS THE CELLS of the batch, adaLN final projection (stDiff_model.py:145-243).
 
     Extra (not in the reference): ``compute_dtype`` -- "fp32" (default: exact-fp32 MFMA, matches the reference to
-    ~1e-6) or "bf16" (bf16 MFMA with fp32 accumulation); also settable through the STDIFF_DTYPE environment variable
-    or ``model.set_compute_dtype()``."""
+    ~1e-6), "bf16" (bf16 MFMA with fp32 accumulation) or, for sampling only, "fp16" (IEEE fp16 MFMA operands, fp32
+    accumulation and residual stream: the same speed as bf16 with 8x smaller operand rounding); also settable through
+    the STDIFF_DTYPE environment variable or ``model.set_compute_dtype()``."""
 
     def __init__(self, input_size, hidden_size, depth, dit_type, num_heads, classes, mlp_ratio=4.0, **kwargs):
         super().__init__()

@@ -5,7 +5,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from ._lib import F32, check, dt_of, lib, ptr, require_gpu, stream
+from ._lib import F32, check, dt_of, lib, lib_for, ptr, require_gpu, stream
 
 
 def round_up(a, b):
@@ -17,7 +17,7 @@ def gemm(A, W, bias=None, out=None, out_dtype=None, epi=L.EPI_BIAS, gate=None, r
     """out[M,N] = epi(A[M,K] @ W[N,K]^T + bias). A/W: same dtype (fp32 or bf16), K-contiguous rows -- or, with
     a_kmajor / w_kmajor, given as [K, M] / [K, N] (K rows; need not be a multiple of the K-slab)."""
     require_gpu(A, W, bias, out, gate, res, out2, workspace)
-    bk = 64 if A.dtype == torch.bfloat16 else 16
+    bk = 64 if A.element_size() == 2 else 16
     kA = A.shape[0] if a_kmajor else A.shape[1]
     kW = W.shape[0] if w_kmajor else W.shape[1]
     if a_kmajor and w_kmajor:
@@ -50,7 +50,7 @@ def gemm(A, W, bias=None, out=None, out_dtype=None, epi=L.EPI_BIAS, gate=None, r
         a.C2, a.ldc2 = ptr(out2), out2.stride(0)
     if workspace is not None:          # fp32 scratch for split-K (small outputs with a long K)
         a.workspace, a.workspace_bytes = ptr(workspace), workspace.numel() * workspace.element_size()
-    check(lib().stdiff_gemm(C.byref(a), stream()))
+    check(lib_for(A, W, out, gate, out2).stdiff_gemm(C.byref(a), stream()))
     return out
 
 
@@ -61,7 +61,7 @@ def transpose(x, out=None, rows_pad=None):
     rows_pad = r if rows_pad is None else rows_pad
     if out is None:
         out = torch.empty((c, rows_pad), device=x.device, dtype=x.dtype)
-    check(lib().stdiff_transpose(ptr(x), x.stride(0), ptr(out), out.stride(0), r, c, rows_pad, dt_of(x), stream()))
+    check(lib_for(x, out).stdiff_transpose(ptr(x), x.stride(0), ptr(out), out.stride(0), r, c, rows_pad, dt_of(x), stream()))
     return out
 
 
@@ -72,7 +72,7 @@ def attention_fwd(qkv, cu_rows, max_chunk, heads, out=None, lse=None):
     H = H3 // 3
     if out is None:
         out = torch.empty((R, H), device=qkv.device, dtype=qkv.dtype)
-    check(lib().stdiff_attention_fwd(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(lse), ptr(cu_rows),
+    check(lib_for(qkv, out).stdiff_attention_fwd(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(lse), ptr(cu_rows),
                                      cu_rows.numel() - 1, max_chunk, heads, H // heads, dt_of(qkv), stream()))
     return out
 
@@ -84,7 +84,7 @@ def ln_modulate(x, shift, scale, out=None, out_dtype=None, mean=None, rstd=None)
     assert shift.stride(0) == scale.stride(0) and shift.dtype == scale.dtype
     if out is None:
         out = torch.empty((R, H), device=x.device, dtype=out_dtype or shift.dtype)
-    check(lib().stdiff_ln_modulate(ptr(x), x.stride(0), ptr(shift), ptr(scale), shift.stride(0), dt_of(shift),
+    check(lib_for(shift, out).stdiff_ln_modulate(ptr(x), x.stride(0), ptr(shift), ptr(scale), shift.stride(0), dt_of(shift),
                                    ptr(out), out.stride(0), dt_of(out), ptr(mean), ptr(rstd), R, H, stream()))
     return out
 
@@ -94,7 +94,7 @@ def silu_cond(ycond, temb=None, t_index=None, out=None, out_dtype=torch.float32)
     R, H = ycond.shape
     if out is None:
         out = torch.empty((R, H), device=ycond.device, dtype=out_dtype)
-    check(lib().stdiff_silu_cond(ptr(temb), ptr(t_index), ptr(ycond), ycond.stride(0), ptr(out), out.stride(0),
+    check(lib_for(out).stdiff_silu_cond(ptr(temb), ptr(t_index), ptr(ycond), ycond.stride(0), ptr(out), out.stride(0),
                                  dt_of(out), R, H, stream()))
     return out
 
@@ -105,7 +105,7 @@ def timestep_embedding(t, freqs, out=None, out_dtype=torch.float32):
     R = t.numel()
     if out is None:
         out = torch.empty((R, 256), device=t.device, dtype=out_dtype)
-    check(lib().stdiff_timestep_embedding(ptr(t), ptr(freqs), ptr(out), out.stride(0), dt_of(out), R, stream()))
+    check(lib_for(out).stdiff_timestep_embedding(ptr(t), ptr(freqs), ptr(out), out.stride(0), dt_of(out), R, stream()))
     return out
 
 
@@ -114,7 +114,7 @@ def pack_rows(src, cpad, dtype, out=None):
     R, Cc = src.shape
     if out is None:
         out = torch.empty((R, cpad), device=src.device, dtype=dtype)
-    check(lib().stdiff_pack_rows(ptr(src), src.stride(0), ptr(out), out.stride(0), dt_of(out), R, Cc, cpad, stream()))
+    check(lib_for(out).stdiff_pack_rows(ptr(src), src.stride(0), ptr(out), out.stride(0), dt_of(out), R, Cc, cpad, stream()))
     return out
 
 
@@ -142,7 +142,7 @@ def ddpm_step(x, eps, gt, mask, coef, t_dev, t_first, z_base=None, seed=0, row_o
     if xp is not None:
         a.xp, a.ldxp, a.xp_dtype = ptr(xp), xp.stride(0), dt_of(xp)
     a.R, a.G, a.pred_type = x.shape[0], x.shape[1], pred_type
-    check(lib().stdiff_ddpm_step(C.byref(a), stream()))
+    check(lib_for(xp).stdiff_ddpm_step(C.byref(a), stream()))
 
 
 def advance_timestep(t_dev):
@@ -151,21 +151,21 @@ def advance_timestep(t_dev):
 
 def init_sample(x, gt, mask, z=None, seed=0, row_offset=0, xp=None):
     require_gpu(x, gt, mask, z, xp)
-    check(lib().stdiff_init_sample(ptr(x), ptr(z), seed, row_offset, ptr(gt), ptr(mask), ptr(xp),
+    check(lib_for(xp).stdiff_init_sample(ptr(x), ptr(z), seed, row_offset, ptr(gt), ptr(mask), ptr(xp),
                                    xp.stride(0) if xp is not None else 0, dt_of(xp) if xp is not None else F32,
                                    x.shape[0], x.shape[1], stream()))
 
 
 def add_noise_splice(x, noise, t, sqrt_ac, sqrt_1mac, mask, x_noisy=None, xp=None):
     require_gpu(x, noise, t, sqrt_ac, sqrt_1mac, mask, x_noisy, xp)
-    check(lib().stdiff_add_noise_splice(ptr(x), ptr(noise), ptr(t), ptr(sqrt_ac), ptr(sqrt_1mac), ptr(mask),
+    check(lib_for(xp).stdiff_add_noise_splice(ptr(x), ptr(noise), ptr(t), ptr(sqrt_ac), ptr(sqrt_1mac), ptr(mask),
                                         ptr(x_noisy), ptr(xp), xp.stride(0) if xp is not None else 0,
                                         dt_of(xp) if xp is not None else F32, x.shape[0], x.shape[1], stream()))
 
 
 def masked_mse(pred, noise, mask, loss, dpred=None, dp=None, grad_scale=1.0):
     require_gpu(pred, noise, mask, loss, dpred, dp)
-    check(lib().stdiff_masked_mse(ptr(pred), ptr(noise), ptr(mask), ptr(loss), ptr(dpred), ptr(dp),
+    check(lib_for(dp).stdiff_masked_mse(ptr(pred), ptr(noise), ptr(mask), ptr(loss), ptr(dpred), ptr(dp),
                                   dp.stride(0) if dp is not None else 0, dt_of(dp) if dp is not None else F32,
                                   grad_scale, pred.shape[0], pred.shape[1], stream()))
 
@@ -178,7 +178,7 @@ def attention_bwd(qkv, out, dout, lse, cu_rows, max_chunk, heads, dqkv=None, del
         dqkv = torch.empty_like(qkv)
     if delta is None:
         delta = torch.empty((R, heads), device=qkv.device, dtype=torch.float32)
-    check(lib().stdiff_attention_bwd(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(dout), dout.stride(0),
+    check(lib_for(qkv, out, dout, dqkv).stdiff_attention_bwd(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(dout), dout.stride(0),
                                      ptr(lse), ptr(delta), ptr(dqkv), dqkv.stride(0), ptr(cu_rows),
                                      cu_rows.numel() - 1, max_chunk, R, heads, H // heads, dt_of(qkv), stream()))
     return dqkv
@@ -188,7 +188,7 @@ def ln_modulate_bwd(dy, x, mean, rstd, scale, dx, dshift, dscale, accumulate=Tru
     require_gpu(dy, x, mean, rstd, scale, dx, dshift, dscale)
     R, H = x.shape
     assert dshift.stride(0) == dscale.stride(0)
-    check(lib().stdiff_ln_modulate_bwd(ptr(dy), dy.stride(0), dt_of(dy), ptr(x), x.stride(0), ptr(mean), ptr(rstd),
+    check(lib_for(dy, scale, dshift).stdiff_ln_modulate_bwd(ptr(dy), dy.stride(0), dt_of(dy), ptr(x), x.stride(0), ptr(mean), ptr(rstd),
                                        ptr(scale), scale.stride(0), ptr(dx), dx.stride(0), int(accumulate),
                                        ptr(dshift), ptr(dscale), dshift.stride(0), R, H, stream()))
 
@@ -196,7 +196,7 @@ def ln_modulate_bwd(dy, x, mean, rstd, scale, dx, dshift, dscale, accumulate=Tru
 def gate_bwd(dh, gate, branch, dbranch, dgate):
     require_gpu(dh, gate, branch, dbranch, dgate)
     R, H = dh.shape
-    check(lib().stdiff_gate_bwd(ptr(dh), dh.stride(0), ptr(gate), gate.stride(0), ptr(branch), branch.stride(0),
+    check(lib_for(gate, branch, dbranch, dgate).stdiff_gate_bwd(ptr(dh), dh.stride(0), ptr(gate), gate.stride(0), ptr(branch), branch.stride(0),
                                 ptr(dbranch), dbranch.stride(0), ptr(dgate), dgate.stride(0), dt_of(gate), R, H,
                                 stream()))
 
@@ -205,20 +205,20 @@ def gelu_bwd(dg, u_pre, du):
     require_gpu(dg, u_pre, du)
     R, Cc = dg.shape
     assert dg.stride(0) == u_pre.stride(0) == du.stride(0)
-    check(lib().stdiff_gelu_bwd(ptr(dg), ptr(u_pre), ptr(du), dg.stride(0), dt_of(dg), R, Cc, stream()))
+    check(lib_for(dg, u_pre, du).stdiff_gelu_bwd(ptr(dg), ptr(u_pre), ptr(du), dg.stride(0), dt_of(dg), R, Cc, stream()))
 
 
 def silu_bwd(ds, c, dc, accumulate=False):
     require_gpu(ds, c, dc)
     R, H = ds.shape
-    check(lib().stdiff_silu_bwd(ptr(ds), ds.stride(0), dt_of(ds), ptr(c), c.stride(0), dt_of(c), ptr(dc),
+    check(lib_for(ds, c, dc).stdiff_silu_bwd(ptr(ds), ds.stride(0), dt_of(ds), ptr(c), c.stride(0), dt_of(c), ptr(dc),
                                 dc.stride(0), dt_of(dc), int(accumulate), R, H, stream()))
 
 
 def colsum(dY, db, accumulate=False):
     require_gpu(dY, db)
     R, Cc = dY.shape
-    check(lib().stdiff_colsum(ptr(dY), dY.stride(0), dt_of(dY), ptr(db), int(accumulate), R, Cc, stream()))
+    check(lib_for(dY).stdiff_colsum(ptr(dY), dY.stride(0), dt_of(dY), ptr(db), int(accumulate), R, Cc, stream()))
 
 
 def grad_sumsq(g, sumsq):

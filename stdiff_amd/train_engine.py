@@ -43,6 +43,10 @@ class TrainCore:
         if dev.type != "cuda":
             raise RuntimeError("stdiff_amd runs on MI355X only: move the model with .to('cuda') (no CPU fallback)")
         self.device = dev
+        from .engine import F16, parse_dtype
+        if parse_dtype(model.compute_dtype) == F16:
+            raise ValueError("compute_dtype 'fp16' is a sampling format (its gradients would need loss scaling): "
+                             "train in 'bf16' or 'fp32'")
         self.names = [n for n in params if n not in _NO_GRAD]
         # ---- flat parameter / gradient / moment buffers (each tensor starts on a 16-byte boundary)
         offs, total = flat_layout([(n, params[n].numel()) for n in self.names])

@@ -42,7 +42,7 @@ def problem(N, G, fold=0, seed=1):
 
 
 # ---------------------------------------------------------------- configs[0]
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 def test_config0_reverse_step_against_oracle(dtype):
     from stdiff_amd import engine as E
     from stdiff_amd.model.stDiff_scheduler import NoiseScheduler
@@ -71,7 +71,7 @@ def test_config0_reverse_step_against_oracle(dtype):
         out = smp.run([t], z=zz).clone()
     e_eps, e_x = relerr(eps, ref_eps), relerr(out, ref_x)
     print(f"configs[0] {dtype}: eps rel err {e_eps:.3e}, x_(t-1) rel err {e_x:.3e}")
-    tol = FP32_TOL if dtype == "fp32" else BF16_TOL
+    tol = {"fp32": FP32_TOL, "bf16": BF16_TOL, "fp16": 1e-3}[dtype]
     assert e_eps < tol and e_x < tol
     known = mask.astype(bool)
     assert np.array_equal(out.cpu().numpy()[:, known], gt[:, known])
@@ -218,12 +218,12 @@ def test_config2_shape_training_iteration_against_oracle(dtype):
         assert abs(float(gn) - gn_r) < 5e-2 * gn_r
 
 
-# ---------------------------------------------------------------- configs[4]: fp32 vs bf16 over a whole 1000-step loop
+# ---------------------------------------------------------------- configs[4]: fp32 vs bf16 / fp16 over a whole 1000-step loop
 def test_config4_fp32_vs_bf16_full_loop():
     """configs[4]'s model (500 genes, hidden 1024, chunks of 512) on 2048 spots through the WHOLE 1000-step reverse loop
-    in both precisions with the same Philox noise: the bf16 result is compared with the fp32 one per gene (Pearson and
-    cosine over the spots, unknown genes only: the numbers the north star asks to report for bf16), known genes are
-    bit-equal in both."""
+    in all three precisions with the same Philox noise: the bf16 and fp16 results are compared with the fp32 one per
+    gene (Pearson and cosine over the spots, unknown genes only: the numbers the north star asks to report for the
+    16-bit path), known genes are bit-equal in all."""
     from stdiff_amd.metrics import gene_metrics
     from stdiff_amd.model.sample import sample_stDiff
     from stdiff_amd.model.stDiff_scheduler import NoiseScheduler
@@ -231,7 +231,7 @@ def test_config4_fp32_vs_bf16_full_loop():
     N, G, H, depth, heads, B, T = 2048, 500, 1024, 6, 16, 512, 1000
     mask, gt = problem(N, G, fold=2, seed=7)
     res = {}
-    for dtype in ("fp32", "bf16"):
+    for dtype in ("fp32", "bf16", "fp16"):
         m, _ = build(G, H, depth, heads, 4, dtype)
         m.eval()
         dl = get_data_loader(gt, gt, batch_size=B, is_shuffle=False, device=DEV)
@@ -248,3 +248,11 @@ def test_config4_fp32_vs_bf16_full_loop():
     print(f"configs[4] full loop bf16 vs fp32: max rel diff {rel:.3e}; per-gene Pearson min {gm['PCC'].min():.5f} "
           f"median {np.median(gm['PCC']):.5f}; cosine min {gm['cosine'].min():.5f}")
     assert gm["PCC"].min() > 0.999 and gm["cosine"].min() > 0.999
+    assert np.array_equal(res["fp16"][:, known], gt[:, known])
+    g16 = gene_metrics(torch.from_numpy(res["fp16"][:, unk]).to(DEV), torch.from_numpy(res["fp32"][:, unk]).to(DEV),
+                       js=False, spcc=False)
+    a, b = res["fp16"][:, unk].astype(np.float64), res["fp32"][:, unk].astype(np.float64)
+    rel16, l2 = np.abs(a - b).max() / np.abs(b).max(), np.linalg.norm(a - b) / np.linalg.norm(b)
+    print(f"configs[4] full loop fp16 vs fp32: max rel diff {rel16:.3e}, rel-l2 {l2:.3e}; per-gene Pearson min "
+          f"{g16['PCC'].min():.6f}; cosine min {g16['cosine'].min():.6f}")
+    assert g16["PCC"].min() > 0.9999 and g16["cosine"].min() > 0.9999 and g16["PCC"].min() >= gm["PCC"].min()

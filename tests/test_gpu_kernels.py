@@ -36,17 +36,20 @@ def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
+TDT = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}
+
+
 def to_dt(x, dt):
-    return x.to(DEV).to(torch.bfloat16 if dt == "bf16" else torch.float32).contiguous()
+    return x.to(DEV).to(TDT[dt]).contiguous()
 
 
 def q(x, dt):
     """operand as the kernel sees it, back in fp32"""
-    return x.to(torch.bfloat16).float() if dt == "bf16" else x
+    return x.to(TDT[dt]).float()
 
 
 # ---------------------------------------------------------------- GEMM
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 128), (77, 1000, 192), (512, 3072, 1024), (1, 8, 64),
                                    (300, 33, 64)])
 def test_gemm_bias(ops, L, dt, M, N, K):
@@ -54,9 +57,9 @@ def test_gemm_bias(ops, L, dt, M, N, K):
     ref = q(A, dt) @ q(W, dt).T + b
     out = ops.gemm(to_dt(A, dt), to_dt(W, dt), b.to(DEV), out_dtype=torch.float32)
     assert relerr(out, ref) < (2e-6 if dt == "fp32" else 2e-6 * 8)
-    if dt == "bf16":
+    if dt != "fp32":                 # 16-bit output: one rounding of the result (2^-9 bf16, 2^-12 fp16)
         out16 = ops.gemm(to_dt(A, dt), to_dt(W, dt), b.to(DEV))
-        assert out16.dtype == torch.bfloat16 and relerr(out16, ref) < 5e-3
+        assert out16.dtype == TDT[dt] and relerr(out16, ref) < (5e-3 if dt == "bf16" else 6e-4)
 
 
 def test_gemm_layout_exact(ops):
@@ -153,28 +156,30 @@ def test_gemm_k_major_operands(ops, L, dt, M, N, K):
     assert relerr(sub, ref[:sub.shape[0]]) < tol                      # a row subset of a wider K-major operand
 
 
-@pytest.mark.parametrize("variant", ["3", "4", "4s"])
+@pytest.mark.parametrize("variant", ["3", "4", "4s", "4h"])
 @pytest.mark.parametrize("M,N,K", [(600, 520, 256), (257, 264, 64), (1024, 512, 1024), (300, 1000, 192)])
 def test_gemm_256_kernel_all_epilogues(ops, L, M, N, K, variant, monkeypatch):
     """The persistent 256 x 256 bf16 kernel forced (STDIFF_GEMM_TILE=3 is read per call): ragged M / N edges, every
     epilogue kind, fp32 and bf16 outputs, K of 1 / 3 / 4 / 16 slabs (prologue and tail of the refill schedule).  Variant 3 =
     four 16-MFMA phases per slab, 4 = two 32-MFMA phases (the default), 4s = the same with the tiles of a short last
-    round cut into 128-row half units (STDIFF_GEMM_SPLIT_TAIL=1; here every tile is in that round)."""
+    round cut into 128-row half units (STDIFF_GEMM_SPLIT_TAIL=1; here every tile is in that round), 4h = the default
+    kernel of the fp16 build (libstdiff_hip_f16.so)."""
     monkeypatch.setenv("STDIFF_GEMM_TILE", variant[0])
     if variant.endswith("s"):
         monkeypatch.setenv("STDIFF_GEMM_SPLIT_TAIL", "1")
-    dt = "bf16"
+    dt = "fp16" if variant.endswith("h") else "bf16"
+    t16 = 6e-4 if dt == "fp16" else 5e-3          # one rounding of a 16-bit result
     A, W, b = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=K ** -0.5), rnd(N, seed=13, scale=0.1)
     v = q(A, dt) @ q(W, dt).T + b
     Ad, Wd, bd = to_dt(A, dt), to_dt(W, dt), b.to(DEV)
     tol = 3e-5
     assert relerr(ops.gemm(Ad, Wd, bd, out_dtype=torch.float32), v) < tol
     assert relerr(ops.gemm(Ad, Wd, None, out_dtype=torch.float32), v - b) < tol
-    assert relerr(ops.gemm(Ad, Wd, bd), v) < 5e-3
+    assert relerr(ops.gemm(Ad, Wd, bd), v) < t16
     assert relerr(ops.gemm(Ad, Wd, bd, out_dtype=torch.float32, epi=L.EPI_SILU), F.silu(v)) < tol
     assert relerr(ops.gemm(Ad, Wd, bd, out_dtype=torch.float32, epi=L.EPI_GELU), F.gelu(v)) < tol
     g16 = ops.gemm(Ad, Wd, bd, epi=L.EPI_GELU)                      # bf16 output: the polynomial GELU
-    assert relerr(g16, F.gelu(v)) < 5e-3
+    assert relerr(g16, F.gelu(v)) < t16
     res, gate = rnd(M, N, seed=7), rnd(M, 3 * N, seed=8)
     gd = to_dt(gate, dt)
     h = res.to(DEV).clone()
@@ -187,7 +192,7 @@ def test_gemm_256_kernel_all_epilogues(ops, L, M, N, K, variant, monkeypatch):
     o1 = torch.empty(M, N, device=DEV, dtype=Ad.dtype)
     o2 = torch.empty(M, N, device=DEV, dtype=Ad.dtype)
     ops.gemm(Ad, Wd, bd, out=o1, epi=L.EPI_GELU_SAVE, out2=o2)
-    assert relerr(o1, F.gelu(v)) < 5e-3 and relerr(o2, v) < 5e-3
+    assert relerr(o1, F.gelu(v)) < t16 and relerr(o2, v) < t16
 
 
 def test_gelu_polynomial_accuracy(ops, L, monkeypatch):
@@ -238,7 +243,7 @@ def attn_ref(qkv, lens, heads):
     return torch.cat(outs), torch.cat(lses)
 
 
-@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("d,heads,lens", [(32, 4, [96]), (32, 16, [40, 40, 16]), (64, 16, [512, 130, 1]),
                                           (128, 16, [200, 64]), (64, 2, [2048, 33])])
 def test_attention_fwd(ops, dt, d, heads, lens):
@@ -249,7 +254,8 @@ def test_attention_fwd(ops, dt, d, heads, lens):
     cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=DEV)
     lse = torch.empty(R, heads, device=DEV)
     out = ops.attention_fwd(to_dt(qkv, dt), cu, max(lens), heads, lse=lse)
-    assert relerr(out, ref) < (1e-5 if dt == "fp32" else 1.2e-2)   # bf16: P and the output are rounded to bf16
+    # 16-bit: P and the output are rounded to the operand format
+    assert relerr(out, ref) < {"fp32": 1e-5, "bf16": 1.2e-2, "fp16": 1.5e-3}[dt]
     assert relerr(lse, lse_ref) < 1e-5
 
 

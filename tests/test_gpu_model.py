@@ -3,7 +3,9 @@ reference (tests/golden, tools/make_goldens.py) and against the oracle on fresh 
 
 Tolerances (north_star): fp32 path <= 1e-5 of the output scale per denoiser call (teacher forced);
 bf16 path: bf16 operands with fp32 accumulation cannot reach 1e-3 through 24 chained GEMMs -- the measured error
-is asserted at <= 3e-2 of the output scale and per-gene Pearson/cosine >= 0.999 is required instead."""
+is asserted at <= 3e-2 of the output scale and per-gene Pearson/cosine >= 0.999 is required instead (DESIGN.md);
+fp16 path (libstdiff_hip_f16.so: IEEE fp16 operands, otherwise the same kernels): <= 1e-3 of the output scale per
+denoiser call, i.e. the north star's 16-bit tolerance, at the bf16 path's speed."""
 import os
 
 import numpy as np
@@ -17,6 +19,8 @@ from oracle import cpu_ref as O  # noqa: E402
 DEV = "cuda:0"
 FP32_TOL = 1e-5
 BF16_TOL = 3e-2
+FP16_TOL = 1e-3
+TOL = {"fp32": FP32_TOL, "bf16": BF16_TOL, "fp16": FP16_TOL}
 
 
 def relerr(a, b):
@@ -39,7 +43,7 @@ def build(G, H, depth, heads, seed, dtype):
     return m.to(DEV).eval(), p
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("case", ["A", "B", "C", "D"])
 def test_forward_golden(golden_dir, case, dtype):
     g = np.load(os.path.join(golden_dir, f"g1_forward_{case}.npz"))
@@ -50,8 +54,8 @@ def test_forward_golden(golden_dir, case, dtype):
     assert eps.shape == (N, G) and eps.dtype == torch.float32
     e = relerr(eps, g["eps"])
     print(f"forward {case} {dtype}: rel err {e:.3e}")
-    assert e < (FP32_TOL if dtype == "fp32" else BF16_TOL)
-    if dtype == "bf16":
+    assert e < TOL[dtype]
+    if dtype != "fp32":
         assert pearson_cols(eps.cpu().numpy(), g["eps"]).min() > 0.999
 
 
@@ -75,7 +79,7 @@ def _g5(golden_dir):
     return g, [int(v) for v in g["cfg"]]
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 def test_sampling_teacher_forced(golden_dir, dtype):
     """G5 per-step denoiser output with the reference's own x_t fed at every step."""
     from stdiff_amd import engine as E
@@ -92,7 +96,7 @@ def test_sampling_teacher_forced(golden_dir, dtype):
             smp.set_x(torch.from_numpy(g["x_in"][i]).to(DEV))
             worst = max(worst, relerr(smp.denoise_only(t), g["eps"][i]))
     print(f"teacher-forced per-step eps {dtype}: worst rel err {worst:.3e}")
-    assert worst < (FP32_TOL if dtype == "fp32" else BF16_TOL)
+    assert worst < TOL[dtype]
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -119,12 +123,13 @@ def test_sample_stdiff_free_running_fp32(golden_dir, use_graph):
     assert relerr(part, np.load(os.path.join(golden_dir, "g5_partial.npz"))["final"]) < 1e-4
 
 
-def test_sample_bf16_final_quality(golden_dir):
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_sample_16bit_final_quality(golden_dir, dtype):
     from stdiff_amd.model.sample import sample_stDiff
     from stdiff_amd.model.stDiff_scheduler import NoiseScheduler
     from stdiff_amd.process.data import get_data_loader
     g, (N, G, H, depth, heads, seed, T, B) = _g5(golden_dir)
-    m, _ = build(G, H, depth, heads, seed, "bf16")
+    m, _ = build(G, H, depth, heads, seed, dtype)
     dl = get_data_loader(g["gt"], g["gt"], batch_size=B, is_shuffle=False)
     out = sample_stDiff(m, dl, NoiseScheduler(T, beta_schedule="cosine"), mask=g["mask"], gt=g["gt"], device=DEV,
                         num_step=T, sample_shape=(N, G), is_condi=True, sample_intermediate=T, x_T=g["x_T"],
@@ -133,12 +138,16 @@ def test_sample_bf16_final_quality(golden_dir):
     pr = pearson_cols(out[:, unk], g["final"][:, unk])
     a, b = out[:, unk].astype(np.float64), g["final"][:, unk].astype(np.float64)
     cos = (a * b).sum(0) / np.sqrt((a * a).sum(0) * (b * b).sum(0))
-    print(f"bf16 free-running final: rel err {relerr(out, g['final']):.3e}, per-gene Pearson min {pr.min():.5f} "
-          f"median {np.median(pr):.5f}, cosine min {cos.min():.5f}")
+    e = relerr(out, g["final"])
+    l2 = float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    print(f"{dtype} free-running final: max-norm rel err {e:.3e}, rel-l2 over the unknown genes {l2:.3e}, per-gene "
+          f"Pearson min {pr.min():.5f} median {np.median(pr):.5f}, cosine min {cos.min():.5f}")
     assert pr.min() > 0.99 and cos.min() > 0.99
+    if dtype == "fp16":     # 20 chained steps of a coarse schedule amplify the per-call error (fp32: 5e-7 -> 2e-6)
+        assert e < 1e-2 and l2 < FP16_TOL and pr.min() > 0.99999
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp16"])
 def test_ragged_chunks_against_oracle(dtype):
     """Edge cases of the chunked denoiser (model/sample.py:9-18): a 1-row chunk, a chunk shorter than one key tile,
     one longer than a query tile (129 rows: tails in every tile loop), per-row timesteps; each chunk attends only
@@ -158,7 +167,7 @@ def test_ragged_chunks_against_oracle(dtype):
             a += ln
     e = relerr(got, torch.cat(ref))
     print(f"ragged chunks {dtype}: rel err {e:.3e}")
-    assert e < (FP32_TOL if dtype == "fp32" else BF16_TOL)
+    assert e < TOL[dtype]
 
 
 def test_tiny_and_empty_inputs():
