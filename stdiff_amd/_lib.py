@@ -108,6 +108,7 @@ def lib(fp16=False):
     L = _libs.get(bool(fp16))
     if L is None:
         path = LIB_PATH_F16 if fp16 else LIB_PATH
+        path = os.environ.get("STDIFF_LIB_F16" if fp16 else "STDIFF_LIB", path)     # A/B timing of another build
         base = os.path.basename(path)
         if not os.path.isfile(path):
             raise RuntimeError(

@@ -51,7 +51,11 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef float f32x2_cv __attribute__((ext_vector_type(2)));
 typedef h16 bf16x2_cv __attribute__((ext_vector_type(2)));
 #ifdef STDIFF_H16_FP16
+#ifdef STDIFF_H16_NOSAT   // A/B timing only: conversions overflow to inf
+__device__ __forceinline__ float h16_sat(float f) { return f; }
+#else
 __device__ __forceinline__ float h16_sat(float f) { return __builtin_amdgcn_fmed3f(f, -65504.0f, 65504.0f); }
+#endif
 __device__ __forceinline__ float bf2f(bf16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (_Float16)h16_sat(f)); }  // RNE
 __device__ __forceinline__ float bf_lo(unsigned u) { return bf2f((bf16_t)(u & 0xffffu)); }
