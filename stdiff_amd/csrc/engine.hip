@@ -100,7 +100,7 @@ extern "C" int stdiff_graph_end(void* stream, void** graph_exec_out) {
     if (!g) return STDIFF_ERR_STATE;
     hipGraphExec_t ex = nullptr;
     e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     if (e != hipSuccess) return (int)e;
     *graph_exec_out = (void*)ex;
     return STDIFF_OK;
