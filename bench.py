@@ -138,17 +138,12 @@ def measure_hbm_kernels(eng, ws, sched, gt, mask, dtype, reps=10):
     return out
 
 
-def alt_sampling_leg(dtype, dev, lens, gt, mask, sched, rank, R, streams, steps=20, warmup=5):
-    """The same reverse step timed in another 16-bit operand format (single GPU, reported next to the headline).
-    The lanes reuse the HIP streams of the headline leg: a process has 4 hardware queues, and two fresh streams may
-    land on one queue, which serialises the lanes."""
+def alt_sampling_leg(dtype, dev, lens, gt, mask, sched, rank, R, lanes, steps=20, warmup=5):
+    """The same reverse step timed in another 16-bit operand format (single GPU, reported next to the headline)."""
     from stdiff_amd import engine as E
     model = build_model(dtype, dev)
     with torch.no_grad():
-        smp = E.LanedSampler(model.engine(), sched, lens, gt, gt, mask, seed=1234, row_offset=rank * R,
-                             lanes=max(1, len(streams)))
-        for part, st in zip(smp.parts, streams):
-            part.stream = st
+        smp = E.LanedSampler(model.engine(), sched, lens, gt, gt, mask, seed=1234, row_offset=rank * R, lanes=lanes)
         smp.init()
         smp.run(list(range(T))[::-1][:1])
         smp.run_more(warmup)
@@ -342,13 +337,13 @@ def main():
         with torch.no_grad():
             rec["hbm_kernels"] = measure_hbm_kernels(eng, eng.workspace(lens, lane=99), sched, gt, mask, args.dtype)
         if world == 1 and not args.no_train:
-            streams = [p.stream for p in smp.parts if p.stream is not None]
+            lanes = len(smp.parts)
             del smp
             torch.cuda.empty_cache()
             rec["train"] = train_throughput(train_dtype, dev)
             if args.dtype == "fp16" and not args.no_graph:      # after the training leg: tools/roofline_check.py
                 torch.cuda.empty_cache()                        # takes the GEMM launches before it as the roofline ones
-                rec["bf16_operands"] = alt_sampling_leg("bf16", dev, lens, gt, mask, sched, rank, R, streams)
+                rec["bf16_operands"] = alt_sampling_leg("bf16", dev, lens, gt, mask, sched, rank, R, lanes)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
     if world > 1 and not args.no_train:

@@ -159,6 +159,12 @@ int stdiff_ddpm_step(const stdiff_step_args* a, void* stream);
 /* *t_dev -= 1 (one thread; closes a captured reverse step). */
 int stdiff_advance_timestep(int32_t* t_dev, void* stream);
 
+/* `blocks` one-wave workgroups that each wait `microseconds` (<= 100 ms) on the realtime counter and exit.  No
+ * counterpart in the reference: the sampler runs two chunk groups on two HIP streams, and two such kernels launched
+ * on two streams finish in about one period only if the streams' hardware queues really dispatch concurrently --
+ * the host uses that to choose its lane streams. */
+int stdiff_spin_probe(int blocks, int microseconds, void* stream);
+
 /* x_T init of sample_stDiff (model/sample.py:56-60): x = z*(1-mask) + gt*mask, z injected or Philox. */
 int stdiff_init_sample(float* x, const float* z, uint64_t seed, int64_t row_offset, const float* gt, const float* mask,
                        void* xp, int ldxp, int xp_dtype, int R, int G, void* stream);

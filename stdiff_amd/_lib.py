@@ -81,6 +81,7 @@ _SIGS = {
     "stdiff_preprocess_rows": (i32, [vp, i32, vp, i32, i32, i32, f32, f32, vp]),
     "stdiff_ddpm_step": (i32, [C.POINTER(StepArgs), vp]),
     "stdiff_advance_timestep": (i32, [vp, vp]),
+    "stdiff_spin_probe": (i32, [i32, i32, vp]),
     "stdiff_init_sample": (i32, [vp, vp, u64, i64, vp, vp, vp, i32, i32, i32, i32, vp]),
     "stdiff_add_noise_splice": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "stdiff_masked_mse": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp]),

@@ -106,6 +106,12 @@ __global__ void advance_kernel(int32_t* t) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *t -= 1;
 }
 
+// every block waits until the 100 MHz realtime counter has advanced by `ticks` (an exit condition every wave reaches)
+__global__ __launch_bounds__(64) void spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 template <bool VEC, typename TP>
 __global__ __launch_bounds__(256) void init_sample_kernel(float* x, const float* zin, uint64_t seed, int64_t row_offset,
                                                           const float* gt, const float* mask, TP* xp, int ldxp, int R,
@@ -213,6 +219,13 @@ extern "C" int stdiff_ddpm_step(const stdiff_step_args* a, void* stream) {
 extern "C" int stdiff_advance_timestep(int32_t* t_dev, void* stream) {
     STDIFF_CHECK_ARG(t_dev);
     hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t_dev);
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}
+
+extern "C" int stdiff_spin_probe(int blocks, int microseconds, void* stream) {
+    STDIFF_CHECK_ARG(blocks > 0 && blocks <= 4096 && microseconds > 0 && microseconds <= 100000);
+    hipLaunchKernelGGL(spin_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, 100ull * microseconds);
     STDIFF_LAUNCH_STATUS();
     return STDIFF_OK;
 }

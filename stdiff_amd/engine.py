@@ -275,6 +275,44 @@ class ReverseSampler:
             self.graph, self._graph_z = g, (ptr(z), t_first)
 
 
+def concurrent_streams(device, n, candidates=12, spin_us=500):
+    """`n` HIP streams (torch pool) whose hardware queues dispatch CONCURRENTLY.
+
+    A process has few hardware queues (GPU_MAX_HW_QUEUES, 4 here) and the runtime maps streams onto them; two streams
+    that share a queue -- or two queues the command processor serves from one pipe -- run their kernels one after the
+    other, and the lanes then overlap nothing (measured: 6.2 instead of 5.2 ms per reverse step for the third and
+    fourth stream of the pool).  Probe: 64 idle one-wave workgroups for `spin_us` on each of two streams finish in one
+    period when the streams are concurrent and in two when they are not (stdiff_spin_probe)."""
+    import time
+    if n <= 1 or os.environ.get("STDIFF_LANE_PROBE", "1") == "0":
+        return [torch.cuda.Stream(device=device) for _ in range(n)]
+
+    def pair_ok(a, b):
+        best = float("inf")
+        for _ in range(2):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for st in (a, b):
+                with torch.cuda.stream(st):
+                    ops.spin_probe(64, spin_us)
+            torch.cuda.synchronize(device)
+            best = min(best, time.perf_counter() - t0)
+        return best < 1.6e-6 * spin_us
+
+    with torch.cuda.device(device):
+        ops.spin_probe(1, 1)                             # loads the code object outside the timed launches
+        chosen, spare = [], []
+        for _ in range(candidates):
+            st = torch.cuda.Stream(device=device)
+            if all(pair_ok(st, c) for c in chosen):
+                chosen.append(st)
+                if len(chosen) == n:
+                    return chosen
+            else:
+                spare.append(st)
+    return (chosen + spare + [torch.cuda.Stream(device=device) for _ in range(n)])[:n]
+
+
 def default_lanes(chunk_lens):
     """Concurrent lanes per device: 2 when each lane still fills the chip (STDIFF_LANES overrides)."""
     env = os.environ.get("STDIFF_LANES")
@@ -317,6 +355,9 @@ class LanedSampler:
             c0, r0 = c0 + n, r1
         self.bounds = [(p.row_offset - row_offset, p.row_offset - row_offset + p.ws.R) for p in self.parts]
         self.use_graph = use_graph
+        if use_graph and len(self.parts) > 1:           # lane streams that really overlap (see concurrent_streams)
+            for p, st in zip(self.parts, concurrent_streams(engine.pw.device, len(self.parts))):
+                p.stream = st
 
     def init(self, x_T=None):
         for p, (a, b) in zip(self.parts, self.bounds):

@@ -149,6 +149,11 @@ def advance_timestep(t_dev):
     check(lib().stdiff_advance_timestep(ptr(t_dev), stream()))
 
 
+def spin_probe(blocks, microseconds):
+    """`blocks` idle one-wave workgroups for `microseconds` on the current stream (stream-concurrency probe)."""
+    check(lib().stdiff_spin_probe(int(blocks), int(microseconds), stream()))
+
+
 def init_sample(x, gt, mask, z=None, seed=0, row_offset=0, xp=None):
     require_gpu(x, gt, mask, z, xp)
     check(lib_for(xp).stdiff_init_sample(ptr(x), ptr(z), seed, row_offset, ptr(gt), ptr(mask), ptr(xp),
