@@ -91,7 +91,7 @@ def measure_gemm_roofline(eng, ws, dtype, reps=3):
     achieved = flops / len(launches) / (avg_ms * 1e-3) / 1e12
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "gemm_traffic.json")      # PMC-derived HBM bytes per launch, if collected
-    if os.path.isfile(tfile):
+    if os.path.isfile(tfile) and ws.R == 20000:                       # collected at the default row count only
         traffic = json.load(open(tfile)).get(dtype)
     return {"bound": "mfma", "kernel": "gemm256q_kernel (+ gemm_nt_kernel<16-bit> where its grid fits better)" if dtype != "fp32"
             else "gemm_nt_kernel<float>", "achieved": round(achieved, 1),
