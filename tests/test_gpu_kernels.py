@@ -62,6 +62,43 @@ def test_gemm_bias(ops, L, dt, M, N, K):
         assert out16.dtype == TDT[dt] and relerr(out16, ref) < (5e-3 if dt == "bf16" else 6e-4)
 
 
+def test_fp16_conversions_saturate(ops, L):
+    """The fp16 build never writes inf: results beyond +-65504 are clamped (GEMM epilogues, LN-modulate, pack_rows)."""
+    M, N, K = 256, 256, 64
+    A = torch.full((M, K), 2000.0)
+    W = torch.ones(N, K)
+    W[N // 2:] = -1.0
+    out = ops.gemm(to_dt(A, "fp16"), to_dt(W, "fp16"), None)                 # |v| = 128000 > 65504
+    assert out.dtype == torch.float16 and bool(torch.isfinite(out).all())
+    assert float(out[:, :N // 2].min()) == 65504.0 and float(out[:, N // 2:].max()) == -65504.0
+    exact = ops.gemm(to_dt(A, "fp16"), to_dt(W, "fp16"), None, out_dtype=torch.float32)
+    assert float(exact.abs().min()) == 128000.0                                # the fp32 accumulators are exact
+    big = torch.tensor([[1e6, -1e6, 3.0, 70000.0] * 16], device=DEV)
+    p = ops.pack_rows(big, 64, torch.float16)
+    assert p[0, :4].tolist() == [65504.0, -65504.0, 3.0, 65504.0]
+
+
+def test_lane_streams_are_concurrent(ops):
+    """engine.concurrent_streams: distinct streams whose spin probes overlap (one period, not two)."""
+    import time
+    from stdiff_amd import engine as E
+    a, b = E.concurrent_streams(torch.device(DEV), 2)
+    assert a.cuda_stream != b.cuda_stream
+    ops.spin_probe(1, 1)
+    best = 1e9
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for st in (a, b):
+            with torch.cuda.stream(st):
+                ops.spin_probe(64, 2000)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    assert 1.9e-3 < best < 3.2e-3, best
+    with pytest.raises(ValueError):
+        ops.spin_probe(0, 10)
+
+
 def test_gemm_layout_exact(ops):
     """A = I against an ASYMMETRIC integer W: catches any row/col or k-permutation slip exactly."""
     for dt, K in (("bf16", 128), ("fp32", 64)):
