@@ -1141,7 +1141,12 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
         // few tiles x long K (batch-sized training GEMMs): one block per tile would walk K alone on a mostly idle chip
         const long tiles = (long)p.tiles_m * p.tiles_n;
         const int nk = a->K / bk, ldws = (a->N + 3) & ~3;
-        int S = (int)fmin(fmin(16.0, nk / 4.0), 384.0 / tiles);
+        // Target: ONE block per CU.  Measured on the 512-cell training step (STDIFF_SPLITK_BLOCKS = 128 ... 512): 256
+        // blocks give 3.71 ms (bf16) / 7.30 ms (fp32) against 3.82 / 7.81 for 384 and 3.99 for 512 -- more slices are
+        // more partial-product traffic for the reduce kernel than the second block per CU wins back.
+        static const int smax = [] { const char* e = getenv("STDIFF_SPLITK_MAX"); return e && atoi(e) > 0 ? atoi(e) : 16; }();
+        static const int sblocks = [] { const char* e = getenv("STDIFF_SPLITK_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : cu_count(); }();
+        int S = (int)fmin(fmin((double)smax, nk / 4.0), (double)sblocks / tiles);
         const long long per = (long long)a->M * ldws * 4;
         if (S > 1 && per * S > a->workspace_bytes) S = (int)(a->workspace_bytes / per);
         if (S > 1) {
