@@ -137,5 +137,13 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+static inline int cu_count() {      // CUs of the current device (one process drives one GPU model: cached once)
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t dtype_size(int dt) { return dt == STDIFF_BF16 ? 2 : 4; }

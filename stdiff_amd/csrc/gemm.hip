@@ -1058,15 +1058,6 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* in, int ldi, T*
     }
 }
 
-inline int cu_count() {      // CUs of the current device (one process drives one GPU model: cached once)
-    static const int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
-    return n;
-}
-
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 inline bool al8(const void* p) { return ((uintptr_t)p & 7) == 0; }
 
