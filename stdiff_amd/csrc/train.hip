@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, int64_t n, f
     float acc = 0.f;
     const int64_t nv = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
-        f32x4 v = *(const f32x4*)(g + 4 * i);
+        f32x4 v = __builtin_nontemporal_load((const f32x4*)(g + 4 * i));
         acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -383,7 +383,9 @@ extern "C" int stdiff_colsum(const void* dY, int ld, int dtype, float* db, int a
 extern "C" int stdiff_grad_sumsq(const float* grads, int64_t n, float* sumsq, void* stream) {
     STDIFF_CHECK_ARG(grads && sumsq && n >= 0 && al16(grads));
     if (n == 0) return STDIFF_OK;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(ew_grid((size_t)n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, grads, n, sumsq);
+    static const int sblocks = [] { const char* e = getenv("STDIFF_SUMSQ_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 4 * cu_count(); }();
+    const unsigned gridx = (unsigned)std::min<size_t>(((size_t)n / 4 + 256) / 256, (size_t)sblocks);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(gridx), dim3(256), 0, (hipStream_t)stream, grads, n, sumsq);
     STDIFF_LAUNCH_STATUS();
     return STDIFF_OK;
 }
