@@ -6,10 +6,12 @@
 // operand) so a lane ends up holding 4 CONSECUTIVE n of one m.  The backward contractions (dW = dY^T X, dX = dY W)
 // are the same product with one or both operands K-MAJOR; the 128 x 128 kernel reads those as they lie.
 //
-// Two kernels:
-//   gemm256p_kernel  bf16, 256 x 256 block tile, 8 waves, persistent (one workgroup per CU walks the tiles), LDS-DMA
-//                    staging, 4 phases per K-slab with counted waits and two staggered wave groups (details above
-//                    the kernel).  Used when the output has >= 128 tiles.
+// Kernels:
+//   gemm256q_kernel  16-bit operands (bf16, or fp16 in the -DSTDIFF_H16_FP16 build), 256 x 256 block tile, 8 waves,
+//                    persistent (one workgroup per CU walks the tiles), LDS-DMA staging, 2 phases of 32 MFMAs per
+//                    K-slab with counted waits and two staggered wave groups.  The default when the output has
+//                    >= 128 tiles.  gemm256p_kernel is its 4-phase predecessor (STDIFF_GEMM_TILE=3: A/B timing and
+//                    a second implementation for the tests).
 //   gemm_nt_kernel   bf16 or exact-fp32, 128 x 128 tile, 4 waves, register-staged double buffer, 2 blocks per CU;
 //                    optional K-major operands (transposed LDS reads) and deterministic split-K through a caller
 //                    workspace.  bf16: v_mfma_f32_16x16x32_bf16;  f32: v_mfma_f32_16x16x4_f32 (a k-ordered fp32
