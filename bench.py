@@ -206,15 +206,16 @@ def train_throughput(dtype, dev, steps=20, warmup=5, dist=None, rank=0, world=1)
     eng = TrainEngine(model, lr=1e-4, diffusion_step=T, mask=O.kfold_mask(G, 0))
     assert eng.world == world
     st = torch.from_numpy(O.synth_expression(8 * BATCH, G, 1 + rank) * 2 - 1).to(dev)
+    graph = world == 1                     # one hipGraph per iteration (parallel dW branches); DDP steps are eager
     for i in range(warmup):
-        eng.step(st[:BATCH], st[:BATCH])
+        eng.step(st[:BATCH], st[:BATCH], use_graph=graph)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         lo = (i % 8) * BATCH
-        eng.step(st[lo:lo + BATCH], st[lo:lo + BATCH])
+        eng.step(st[lo:lo + BATCH], st[lo:lo + BATCH], use_graph=graph)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     if dist is not None:

@@ -26,9 +26,11 @@ def normal_train_stDiff(model,
     model.to(device)
     model.train()
     eng = TrainEngine(model, lr=lr, diffusion_step=diffusion_step, mask=mask)
-    # STDIFF_TRAIN_GRAPH=1 replays each iteration as one hipGraph; off by default: at ~345 nodes the ROCm graph launch
-    # costs more than the Python enqueue it replaces (measured 5.27 vs 4.93 ms per 512-cell step at H=1024)
-    use_graph = os.environ.get("STDIFF_TRAIN_GRAPH", "0") == "1"
+    # Each iteration is replayed as one hipGraph per batch size (STDIFF_TRAIN_GRAPH=0: eager enqueue).  The graph has
+    # the weight-gradient GEMMs on parallel branches (train_engine.py), which the eager enqueue cannot afford:
+    # 3.42 against 3.55 ms per 512-cell step at H=1024.  With a process group the step is always eager (the bucketed
+    # all-reduce is issued from the host between backward segments).
+    use_graph = os.environ.get("STDIFF_TRAIN_GRAPH", "1") == "1"
     dev = eng.device
     t_epoch = tqdm(range(num_epoch), ncols=100) if is_tqdm else range(num_epoch)
     for epoch in t_epoch:

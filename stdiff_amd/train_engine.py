@@ -83,6 +83,16 @@ class TrainCore:
         # split-K scratch shared by every GEMM of the step (one stream, so uses never overlap): batch-sized outputs
         # have 32-200 tiles, too few to fill 256 CUs unless the long K axes are cut too
         self.ws_splitk = torch.empty(16 << 20, device=dev, dtype=torch.float32)
+        # The weight-gradient contractions (dW = dY^T X, db = colsum dY) are leaves of the backward graph.  While an
+        # iteration is being CAPTURED into a hipGraph they are issued on a side stream (own split-K scratch), so the
+        # graph gets parallel branches next to the dX chain: at 512 rows a GEMM is a ~15 us launch that leaves most
+        # of the chip idle.  Only under capture: there the fork/join events are graph edges and cost nothing at
+        # replay; issued eagerly, the 4 event calls per layer make the host the limiter (3.55 -> 4.42 ms per step).
+        # STDIFF_TRAIN_SIDE_STREAM=0 never forks, =2 forks in eager mode too (tests).
+        import os
+        self.side_mode = int(os.environ.get("STDIFF_TRAIN_SIDE_STREAM", "1"))
+        self.ws_splitk_side = None
+        self._side, self._side_prev, self._side_on = None, None, False
 
     def refresh_weights(self, pack=True):
         """fp32 master weights -> packed MFMA operands (the backward reads the same [out, in] copies K-major)."""
@@ -115,7 +125,7 @@ class TrainCore:
             mean2=[z(C, dt=f32) for _ in range(D)], rstd2=[z(C, dt=f32) for _ in range(D)],
             fmod=z(C, 2 * H), xnf=z(C, H), meanf=z(C, dt=f32), rstdf=z(C, dt=f32), eps=z(C, G, dt=f32),
             # backward scratch
-            deps=z(C, Gp), dh=z(C, H, dt=f32), dxn=z(C, H), dmod=z(C, 6 * H), dfmod=z(C, 2 * H), dbr=z(C, H),
+            deps=z(C, Gp), dh=z(C, H, dt=f32), dxn=z(C, H), dmod=[z(C, 6 * H), z(C, 6 * H)], dfmod=z(C, 2 * H), dbr=z(C, H),
             du=z(C, 4 * H), dupre=z(C, 4 * H), do=z(C, H), dqkv=z(C, 3 * H), delta=z(C, self.heads, dt=f32),
             ds32=z(C, H, dt=f32), dc=z(C, H, dt=f32), dcT_=z(C, H), de1=z(C, H), da1=z(C, H), dhT_=z(C, H),
         )
@@ -124,8 +134,23 @@ class TrainCore:
         self._acts[C] = a
         return a
 
-    def _gemm(self, *args, **kw):
-        return ops.gemm(*args, workspace=self.ws_splitk, **kw)
+    def _gemm(self, *args, side=False, **kw):
+        return ops.gemm(*args, workspace=self.ws_splitk_side if side else self.ws_splitk, **kw)
+
+    def _side_begin(self):
+        """Decide whether this backward pass forks its weight gradients onto the side stream."""
+        self._side_prev, self._side_on = None, False
+        if self.side_mode == 0 or (self.side_mode == 1 and not torch.cuda.is_current_stream_capturing()):
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self.ws_splitk_side = torch.empty(16 << 20, device=self.device, dtype=torch.float32)
+        self._side_on = True
+
+    def _side_join(self):
+        """The caller's stream waits for every weight gradient issued so far."""
+        if self._side_on and self._side_prev is not None:
+            torch.cuda.current_stream().wait_event(self._side_prev)
 
     def _lin(self, name):
         return self.pw.w[name + ".weight"], self.pw.b(name + ".bias")
@@ -173,16 +198,35 @@ class TrainCore:
     def _dW(self, a, name, dY, X, rows=None):
         """grad[name.weight] = dY^T X ; grad[name.bias] = colsum(dY).  Both operands are read K-major ([batch, .]) as
         they lie: no transposed copies, and a batch that is not a multiple of the K-slab is zero-extended in the kernel."""
+        if not self._side_on:
+            return self._dW_enqueue(a, name, dY, X, rows, False)
+        # Fork: the side stream starts when dY is final.  Join, one job late: from here on the caller's stream waits
+        # for the PREVIOUS job.  Between two _dW calls nothing on the caller's stream rewrites the dY / X of the job
+        # just issued (checked call by call in backward(); dmod alternates between two buffers for exactly that
+        # reason), so one job may stay in flight while the dX chain goes on.
+        cur = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        self._side.wait_event(ready)
+        with torch.cuda.stream(self._side):
+            self._dW_enqueue(a, name, dY, X, rows, True)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        if self._side_prev is not None:
+            cur.wait_event(self._side_prev)
+        self._side_prev = done
+
+    def _dW_enqueue(self, a, name, dY, X, rows, side):
         gw = self.g[name + ".weight"]
         m = gw.shape[0] if rows is None else rows
         if m % 8 or gw.shape[1] % 8:         # odd gene counts: 16-byte column pieces do not exist, go through copies
             Cp = a["Cp"]
             dYT = ops.transpose(dY, rows_pad=Cp)
             XT = ops.transpose(X, rows_pad=Cp)
-            self._gemm(dYT[:m], XT[:gw.shape[1]], None, out=gw)
+            self._gemm(dYT[:m], XT[:gw.shape[1]], None, out=gw, side=side)
         else:
             self._gemm(dY, X[:, :gw.shape[1]] if X.shape[1] != gw.shape[1] else X, None, out=gw, M=m, a_kmajor=True,
-                       w_kmajor=True)
+                       w_kmajor=True, side=side)
         ops.colsum(dY[:, :m] if rows is not None else dY, self.g[name + ".bias"])
 
     def _dX(self, name, dY, out, epi=L.EPI_BIAS):
@@ -194,6 +238,7 @@ class TrainCore:
         after_bucket(i) is called when the i-th range of bucket_ranges() is final (DDP overlap)."""
         H, D = self.H, self.depth
         deps = a["deps"]
+        self._side_begin()
         # ---- final layer
         self._dW(a, "out_layer.linear", deps, X=a["xnf"], rows=self.G)
         self._dX("out_layer.linear", deps, a["dxn"])
@@ -202,10 +247,11 @@ class TrainCore:
         self._dW(a, "out_layer.adaLN_modulation.1", a["dfmod"], X=a["s"])
         self._dX("out_layer.adaLN_modulation.1", a["dfmod"], a["ds32"])
         if after_bucket:
+            self._side_join()
             after_bucket(0)
         for k in range(D - 1, -1, -1):
             p = f"blks.{k}."
-            mod, dmod = a["mod"][k], a["dmod"]
+            mod, dmod = a["mod"][k], a["dmod"][k & 1]
             # MLP branch: h_{k+1} = hmid + gate_mlp * pm
             ops.gate_bwd(a["dh"], mod[:, 5 * H:6 * H], a["pm"][k], a["dbr"], dmod[:, 5 * H:6 * H])
             self._dW(a, p + "mlp.fc2", a["dbr"], X=a["u"][k])
@@ -228,6 +274,7 @@ class TrainCore:
             self._dW(a, p + "adaLN_modulation.1", dmod, X=a["s"])
             self._dX(p + "adaLN_modulation.1", dmod, a["ds32"], epi=L.EPI_ACCUM)
             if after_bucket:
+                self._side_join()
                 after_bucket(D - k)
         # ---- embeddings: h0 = in_layer(x); c = time_emb(t) + cond_layer(y); s = silu(c)
         ops.pack_rows(a["dh"], H, self.tdt, out=a["dhT_"])
@@ -239,6 +286,8 @@ class TrainCore:
         self._dX("time_emb.mlp.2", a["dcT_"], a["de1"])
         ops.silu_bwd(a["de1"], a["a1"], a["da1"])
         self._dW(a, "time_emb.mlp.0", a["da1"], X=a["e0"])
+        self._side_join()                      # every gradient is final on the caller's stream from here on
+        self._side_on = False
         if after_bucket:
             after_bucket(D + 1)
 

@@ -131,10 +131,13 @@ def test_clip_adamw_matches_torch():
 
 
 # ---------------------------------------------------------------- whole train step vs the reference goldens
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_train_steps_golden_fp32(golden_dir, use_graph):
-    """3 consecutive reference iterations (G6); use_graph=True replays each as one captured hipGraph."""
+@pytest.mark.parametrize("use_graph,side", [(False, "1"), (True, "1"), (True, "0"), (False, "2")])
+def test_train_steps_golden_fp32(golden_dir, use_graph, side, monkeypatch):
+    """3 consecutive reference iterations (G6); use_graph=True replays each as one captured hipGraph, whose weight
+    gradients sit on parallel branches (side stream during capture; side="0": single chain; side="2" forks in the
+    eager enqueue too, which exercises the fork / late-join ordering without a graph)."""
     from stdiff_amd.train_engine import TrainEngine
+    monkeypatch.setenv("STDIFF_TRAIN_SIDE_STREAM", side)
     g = np.load(os.path.join(golden_dir, "g6_train.npz"))
     C, G, H, depth, heads, seed, T = [int(v) for v in g["cfg"]]
     m, p0 = build(G, H, depth, heads, seed, "fp32")
