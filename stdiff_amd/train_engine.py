@@ -168,13 +168,35 @@ class TrainCore:
         w, b = self._lin("cond_layer.0")
         g(a["yp"], w, b, out=a["c"], epi=L.EPI_ADD, res=a["temb"])
         ops.silu_cond(a["c"], out=a["s"])
+        # every adaLN projection depends on s only: under graph capture they go to the side stream as one chain, and
+        # the block chain waits for mod[k] where it first needs it
+        self._side_begin()
+        mod_ready = None
+        if self._side_on:
+            cur = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            self._side.wait_event(ready)
+            mod_ready = []
+            with torch.cuda.stream(self._side):
+                for k in range(D + 1):
+                    name = f"blks.{k}.adaLN_modulation.1" if k < D else "out_layer.adaLN_modulation.1"
+                    w, b = self._lin(name)
+                    g(a["s"], w, b, out=a["mod"][k] if k < D else a["fmod"], side=True)
+                    ev = torch.cuda.Event()
+                    ev.record(self._side)
+                    mod_ready.append(ev)
+            self._side_on = False
         w, b = self._lin("in_layer.0")
         g(a["xp"], w, b, out=a["h"][0])
         for k in range(D):
             p = f"blks.{k}."
             mod = a["mod"][k]
-            w, b = self._lin(p + "adaLN_modulation.1")
-            g(a["s"], w, b, out=mod)
+            if mod_ready is None:
+                w, b = self._lin(p + "adaLN_modulation.1")
+                g(a["s"], w, b, out=mod)
+            else:
+                torch.cuda.current_stream().wait_event(mod_ready[k])
             ops.ln_modulate(a["h"][k], mod[:, 0:H], mod[:, H:2 * H], out=a["xn1"][k], mean=a["mean1"][k], rstd=a["rstd1"][k])
             w, b = self._lin(p + "attn.qkv")
             g(a["xn1"][k], w, b, out=a["qkv"][k])
@@ -187,19 +209,25 @@ class TrainCore:
             g(a["xn2"][k], w, b, out=a["u"][k], epi=L.EPI_GELU_SAVE, out2=a["upre"][k])
             w, b = self._lin(p + "mlp.fc2")
             g(a["u"][k], w, b, out=a["h"][k + 1], epi=L.EPI_GATE_RES, gate=mod[:, 5 * H:6 * H], res=a["hmid"][k], out2=a["pm"][k])
-        w, b = self._lin("out_layer.adaLN_modulation.1")
-        g(a["s"], w, b, out=a["fmod"])
+        if mod_ready is None:
+            w, b = self._lin("out_layer.adaLN_modulation.1")
+            g(a["s"], w, b, out=a["fmod"])
+        else:
+            torch.cuda.current_stream().wait_event(mod_ready[D])
         ops.ln_modulate(a["h"][D], a["fmod"][:, 0:H], a["fmod"][:, H:2 * H], out=a["xnf"], mean=a["meanf"], rstd=a["rstdf"])
         w, b = self._lin("out_layer.linear")
         g(a["xnf"], w, b, out=a["eps"])
         return a["eps"]
 
     # ------------------------------------------------------------------ backward
-    def _dW(self, a, name, dY, X, rows=None):
+    def _dW(self, a, name, dY, X, rows=None, then=None):
         """grad[name.weight] = dY^T X ; grad[name.bias] = colsum(dY).  Both operands are read K-major ([batch, .]) as
         they lie: no transposed copies, and a batch that is not a multiple of the K-slab is zero-extended in the kernel."""
         if not self._side_on:
-            return self._dW_enqueue(a, name, dY, X, rows, False)
+            self._dW_enqueue(a, name, dY, X, rows, False)
+            if then is not None:
+                then(False)
+            return
         # Fork: the side stream starts when dY is final.  Join, one job late: from here on the caller's stream waits
         # for the PREVIOUS job.  Between two _dW calls nothing on the caller's stream rewrites the dY / X of the job
         # just issued (checked call by call in backward(); dmod alternates between two buffers for exactly that
@@ -210,6 +238,8 @@ class TrainCore:
         self._side.wait_event(ready)
         with torch.cuda.stream(self._side):
             self._dW_enqueue(a, name, dY, X, rows, True)
+            if then is not None:               # more work on the same inputs that nothing on the caller's chain needs
+                then(True)
             done = torch.cuda.Event()
             done.record(self._side)
         if self._side_prev is not None:
@@ -229,9 +259,9 @@ class TrainCore:
                        w_kmajor=True, side=side)
         ops.colsum(dY[:, :m] if rows is not None else dY, self.g[name + ".bias"])
 
-    def _dX(self, name, dY, out, epi=L.EPI_BIAS):
+    def _dX(self, name, dY, out, epi=L.EPI_BIAS, side=False):
         """out (+)= dY W  with W [out, in] read K-major (K = out features)."""
-        return self._gemm(dY, self.pw.w[name + ".weight"], None, out=out, epi=epi, w_kmajor=True)
+        return self._gemm(dY, self.pw.w[name + ".weight"], None, out=out, epi=epi, w_kmajor=True, side=side)
 
     def backward(self, a, after_bucket=None):
         """a['deps'] holds d loss / d eps as the packed operand [C, Gp]; fills self.flat_g (overwrite).
@@ -244,8 +274,10 @@ class TrainCore:
         self._dX("out_layer.linear", deps, a["dxn"])
         ops.ln_modulate_bwd(a["dxn"], a["h"][D], a["meanf"], a["rstdf"], a["fmod"][:, H:2 * H], a["dh"],
                             a["dfmod"][:, 0:H], a["dfmod"][:, H:2 * H], accumulate=False)
-        self._dW(a, "out_layer.adaLN_modulation.1", a["dfmod"], X=a["s"])
-        self._dX("out_layer.adaLN_modulation.1", a["dfmod"], a["ds32"])
+        # d loss / d s accumulates over all adaLN projections and is needed only after the last block: its GEMMs ride
+        # with the adaLN weight-gradient jobs (same dY), in issue order on whichever stream runs them
+        self._dW(a, "out_layer.adaLN_modulation.1", a["dfmod"], X=a["s"],
+                 then=lambda sd: self._dX("out_layer.adaLN_modulation.1", a["dfmod"], a["ds32"], side=sd))
         if after_bucket:
             self._side_join()
             after_bucket(0)
@@ -271,14 +303,16 @@ class TrainCore:
             self._dX(p + "attn.qkv", a["dqkv"], a["dxn"])
             ops.ln_modulate_bwd(a["dxn"], a["h"][k], a["mean1"][k], a["rstd1"][k], mod[:, H:2 * H], a["dh"],
                                 dmod[:, 0:H], dmod[:, H:2 * H], accumulate=True)
-            self._dW(a, p + "adaLN_modulation.1", dmod, X=a["s"])
-            self._dX(p + "adaLN_modulation.1", dmod, a["ds32"], epi=L.EPI_ACCUM)
+            self._dW(a, p + "adaLN_modulation.1", dmod, X=a["s"],
+                     then=lambda sd, p=p, dmod=dmod: self._dX(p + "adaLN_modulation.1", dmod, a["ds32"],
+                                                              epi=L.EPI_ACCUM, side=sd))
             if after_bucket:
                 self._side_join()
                 after_bucket(D - k)
         # ---- embeddings: h0 = in_layer(x); c = time_emb(t) + cond_layer(y); s = silu(c)
         ops.pack_rows(a["dh"], H, self.tdt, out=a["dhT_"])
         self._dW(a, "in_layer.0", a["dhT_"], X=a["xp"])
+        self._side_join()                      # ds32 is complete
         ops.silu_bwd(a["ds32"], a["c"], a["dc"])
         ops.pack_rows(a["dc"], H, self.tdt, out=a["dcT_"])
         self._dW(a, "cond_layer.0", a["dcT_"], X=a["yp"])
