@@ -2,6 +2,8 @@
 diffusion loss and the fused clip+AdamW step of normal_train_stDiff (stDiff_train.py:56-81), all through
 libstdiff_hip.so.  Under data parallelism the flat gradient buffer is all-reduced with RCCL (torch.distributed
 backend "nccl"), one bucket per DiT block, overlapped with the rest of the backward pass."""
+import os
+
 import torch
 
 from . import _lib as L
@@ -89,7 +91,6 @@ class TrainCore:
         # of the chip idle.  Only under capture: there the fork/join events are graph edges and cost nothing at
         # replay; issued eagerly, the 4 event calls per layer make the host the limiter (3.55 -> 4.42 ms per step).
         # STDIFF_TRAIN_SIDE_STREAM=0 never forks, =2 forks in eager mode too (tests).
-        import os
         self.side_mode = int(os.environ.get("STDIFF_TRAIN_SIDE_STREAM", "1"))
         self.ws_splitk_side = None
         self._side, self._side_prev, self._side_on = None, None, False
