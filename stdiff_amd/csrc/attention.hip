@@ -199,9 +199,23 @@ __global__ __launch_bounds__(256, ATTN_FWD_OCC) void attn_fwd_kernel(const T* __
     __shared__ __attribute__((aligned(16))) unsigned char kls[BKV * C::RSTR];
     __shared__ __attribute__((aligned(16))) unsigned char vls[BKV * C::TSTR];
 
-    const int chunk = blockIdx.z, hd = blockIdx.y;
+    // XCD-aware order: workgroups go to the 8 XCDs round-robin in linear order, so with the natural (query tile
+    // fastest) order the query tiles of one (chunk, head) -- which all read the same K and V rows -- land on
+    // different L2s.  Remap: linear id L -> XCD x = L % 8 keeps unit (chunk, head) 8 * (j / gx) + x, query tile j % gx
+    // (j = L / 8), so one unit's tiles share an L2 and run back to back.  Needs (heads * chunks) % 8 == 0.
+    int chunk = blockIdx.z, hd = blockIdx.y, qt = blockIdx.x;
+    {
+        const int gx = gridDim.x, units = gridDim.y * gridDim.z;
+        if ((units & 7) == 0) {
+            const int L = blockIdx.x + gx * (blockIdx.y + gridDim.y * blockIdx.z);
+            const int j = L >> 3, unit = ((j / gx) << 3) + (L & 7);
+            qt = j % gx;
+            hd = unit % gridDim.y;
+            chunk = unit / gridDim.y;
+        }
+    }
     const int r0 = cu_rows[chunk], len = cu_rows[chunk + 1] - r0;
-    const int q0 = blockIdx.x * BQ;
+    const int q0 = qt * BQ;
     if (q0 >= len) return;
     const int H = heads * D;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
