@@ -1,19 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- imputed spots/sec of 1000-step masked-DDPM sampling (BASELINE.json metric) on MI355X.
 
-A "step" is ONE reverse-diffusion step (denoiser forward over every chunk + fused DDPM update + known-gene splice +
-timestep advance = one replay of the captured hipGraph) over this rank's whole synthetic spot matrix, resident in
-HBM.  Workload = BASELINE.json configs[1]: 20 000 spots x 1000 genes, hidden 1024, depth 6, 16 heads, chunks of 512
-(the reference batch size), cosine schedule T=1000.   value = spots / (1000 * seconds-per-step), aggregate over ranks.
-Per-step cost does not depend on t, so K timed steps stand for the 1000-step run (stated in `config`).
+Workload = BASELINE.json configs[3], the configuration the metric is quoted on: 1 000 000 synthetic spots x 1024 genes,
+hidden 1024, depth 6, 16 heads, chunks of 512 (the reference batch size; 1954 chunks, the last one 64 rows), cosine
+schedule T=1000, STRONG-scaled: the 1 M spots are sharded chunk-aligned over the N ranks (N = 1 holds all of them),
+no collective in the loop.  A "step" is ONE reverse-diffusion step (denoiser forward over every chunk + fused DDPM
+update + known-gene splice + timestep advance = one replay of the captured hipGraph per lane) over this rank's whole
+shard, resident in HBM.  value = 1 000 000 / (1000 * seconds-per-step, max over ranks).  Per-step cost does not depend
+on t, so K timed steps stand for the 1000-step run (stated in `config`).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|fp16|fp32] [--rows R]
-N>1: launched by torch.distributed.run, one rank per GPU; spots are sharded chunk-aligned over ranks with no
-collective in the loop (weak scaling: every rank holds --rows spots).
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype fp16|bf16|fp32] [--spots S]
+
+--gpus N > 1 without a launcher environment: this process starts N ranks itself (torch.distributed.run, one per GPU,
+RCCL) BEFORE it touches the GPU, relays their output and exits with their status.  Under a launcher (WORLD_SIZE set)
+WORLD_SIZE must equal --gpus.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,14 +28,14 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-G, H, DEPTH, HEADS, BATCH, T = 1000, 1024, 6, 16, 512, 1000
+SPOTS, G, H, DEPTH, HEADS, BATCH, T = 1_000_000, 1024, 1024, 6, 16, 512, 1000
 PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}     # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
 
 
-def build_model(dtype, device):
+def build_model(dtype, device, g=G, h=H):
     from stdiff_amd.model.stDiff_model import DiT_stDiff
     torch.manual_seed(1202)
-    m = DiT_stDiff(input_size=G, hidden_size=H, depth=DEPTH, dit_type='dit', num_heads=HEADS, classes=6,
+    m = DiT_stDiff(input_size=g, hidden_size=h, depth=DEPTH, dit_type='dit', num_heads=HEADS, classes=6,
                    mlp_ratio=4.0, compute_dtype=dtype)
     with torch.no_grad():   # a fresh model outputs exactly 0 (zero-init adaLN/out): re-randomise those
         for lin in [b.adaLN_modulation[-1] for b in m.blks] + [m.out_layer.adaLN_modulation[-1], m.out_layer.linear]:
@@ -44,7 +50,7 @@ def flops_per_row(chunk):
 
 
 def gemm_launches(eng, ws):
-    """(M, N, K, closure) of every dense-contraction launch of one denoiser forward, in order."""
+    """(M, N, K, closure) of every dense-contraction launch of one denoiser forward over the slab `ws`, in order."""
     from stdiff_amd import _lib as L
     from stdiff_amd import ops
     pw = eng.pw
@@ -69,10 +75,13 @@ def gemm_launches(eng, ws):
 
 
 def measure_gemm_roofline(eng, ws, dtype, reps=3):
-    """Average launch duration of the dominant kernel (gemm_nt_kernel) with HIP events on the launch stream, over the
-    33 launches of one forward; achieved = algorithmic FLOPs (2MNK) / time."""
+    """Average launch duration of the dominant kernel (the GEMM) with HIP events on the launch stream, over the 33
+    launches of one denoiser forward of a full row slab (the unit the timed loop launches); achieved = algorithmic
+    FLOPs (2MNK) / time."""
     launches = gemm_launches(eng, ws)
     flops = sum(2.0 * m * n * k for m, n, k, _ in launches)
+    for buf in (ws.xp, ws.s, ws.xn, ws.o, ws.u, ws.h, ws.mod):
+        buf.normal_(0, 0.5)
     for _, _, _, f in launches:
         f()
     torch.cuda.synchronize()
@@ -91,18 +100,22 @@ def measure_gemm_roofline(eng, ws, dtype, reps=3):
     achieved = flops / len(launches) / (avg_ms * 1e-3) / 1e12
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "gemm_traffic.json")      # PMC-derived HBM bytes per launch, if collected
-    if os.path.isfile(tfile) and ws.R == 20000:                       # collected at the default row count only
-        traffic = json.load(open(tfile)).get(dtype)
-    return {"bound": "mfma", "kernel": "gemm256q_kernel (+ gemm_nt_kernel<16-bit> where its grid fits better)" if dtype != "fp32"
-            else "gemm_nt_kernel<float>", "achieved": round(achieved, 1),
-            "peak": PEAK[dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK[dtype], 4), "traffic": traffic,
-            "launches_per_step": len(launches), "avg_launch_us": round(avg_ms * 1e3, 1),
+    if os.path.isfile(tfile):
+        rec = json.load(open(tfile))
+        if rec.get("rows_per_launch") == ws.R:                        # collected at this slab size only
+            traffic = rec.get(dtype)
+    return {"bound": "mfma", "kernel": "gemm256q_kernel" if dtype != "fp32" else "gemm_nt_kernel<float>",
+            "achieved": round(achieved, 1), "peak": PEAK[dtype], "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK[dtype], 4), "traffic": traffic,
+            "rows_per_launch": ws.R, "launches_per_slab": len(launches), "avg_launch_us": round(avg_ms * 1e3, 1),
             "flops_per_launch": flops / len(launches)}
 
 
 def measure_hbm_kernels(eng, ws, sched, gt, mask, dtype, reps=10):
-    """Achieved HBM GB/s of the bandwidth-bound kernels of one reverse step at the full row count (HIP events on the
-    launch stream, `reps` launches each): algorithmic bytes (DESIGN.md section 4 / SURVEY 8d) / average duration."""
+    """Achieved HBM GB/s of the bandwidth-bound kernels of one reverse step at the row count of a slab (HIP events on
+    the launch stream, `reps` launches each): algorithmic bytes (DESIGN.md section 4 / SURVEY 8d) / average duration.
+    At 65 536 rows every launch touches 0.4-1.2 GB, several times the 256 MB Infinity Cache, so back-to-back
+    repetitions are not served from it."""
     from stdiff_amd import ops
     from stdiff_amd.engine import step_coefficients
     R, dev = ws.R, ws.h.device
@@ -114,12 +127,11 @@ def measure_hbm_kernels(eng, ws, sched, gt, mask, dtype, reps=10):
     x = torch.randn(R, G, device=dev)
     ws.h.normal_()
     ws.eps.normal_()
-    ws.mod.normal_()
     cases = {
         "ln_modulate_kernel": (lambda: ops.ln_modulate(ws.h, ws.mod[:, 0:H], ws.mod[:, H:2 * H], out=ws.xn),
                                R * H * (4 + 3 * s_el)),
         "silu_cond_kernel": (lambda: ops.silu_cond(ycond, temb=temb, t_index=t_dev, out=ws.s), R * H * (4 + s_el)),
-        "ddpm_step_kernel": (lambda: ops.ddpm_step(x, ws.eps, gt, mask, coef, t_dev, T // 2, seed=1, xp=ws.xp),
+        "ddpm_step_kernel": (lambda: ops.ddpm_step(x, ws.eps, gt[:R], mask, coef, t_dev, T // 2, seed=1, xp=ws.xp),
                              R * G * (16 + s_el)),
     }
     out = {}
@@ -133,31 +145,38 @@ def measure_hbm_kernels(eng, ws, sched, gt, mask, dtype, reps=10):
         b.record()
         torch.cuda.synchronize()
         us = a.elapsed_time(b) * 1e3 / reps
-        out[name] = {"bytes": nbytes, "us": round(us, 1), "GB/s": round(nbytes / us / 1e3, 1),
+        out[name] = {"rows": R, "bytes": nbytes, "us": round(us, 1), "GB/s": round(nbytes / us / 1e3, 1),
                      "frac_of_8TB/s": round(nbytes / us / 1e3 / 8000.0, 3)}
     return out
 
 
-def alt_sampling_leg(dtype, dev, lens, gt, mask, sched, rank, R, lanes, steps=20, warmup=5):
-    """The same reverse step timed in another 16-bit operand format (single GPU, reported next to the headline)."""
+def alt_sampling_leg(dtype, dev, lens, gt, mask, sched, row_offset, spots_total, lanes, steps, warmup):
+    """The same reverse step over the same spots in another MFMA operand format (reported next to the headline)."""
     from stdiff_amd import engine as E
     model = build_model(dtype, dev)
     with torch.no_grad():
-        smp = E.LanedSampler(model.engine(), sched, lens, gt, gt, mask, seed=1234, row_offset=rank * R, lanes=lanes)
+        smp = E.LanedSampler(model.engine(), sched, lens, gt, gt, mask, seed=1234, row_offset=row_offset, lanes=lanes)
         smp.init()
         smp.run(list(range(T))[::-1][:1])
-        smp.run_more(warmup)
+        if warmup:
+            smp.run_more(warmup)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         smp.run_more(steps)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
-    return {"dtype": dtype, "ms_per_step": round(ms, 4), "value": round(R / (T * ms * 1e-3), 2), "steps": steps}
+        assert bool(torch.isfinite(smp.x[:4096]).all())
+    R = sum(lens)
+    del smp, model
+    torch.cuda.empty_cache()
+    return {"dtype": dtype, "ms_per_step": round(ms, 3), "value": round(R / (T * ms * 1e-3), 2), "steps": steps,
+            "spots": R, "step_tflops": round(sum(n * flops_per_row(n) for n in lens) / (ms * 1e-3) / 1e12, 1),
+            "frac_of_peak": round(sum(n * flops_per_row(n) for n in lens) / (ms * 1e-3) / 1e12 / PEAK[dtype], 4)}
 
 
-def cpu_baseline(rows_chunks=8, steps=12):
+def cpu_baseline(rows_chunks=8, steps=10):
     """The oracle (eager PyTorch fp32 restatement of the reference, oracle/cpu_ref.py) on the host cores, on a bounded
-    sample of the same workload: `rows_chunks` chunks of 512 spots x 1000 genes, `steps` reverse steps."""
+    sample of the same workload: `rows_chunks` chunks of 512 spots x 1024 genes, `steps` reverse steps."""
     from oracle import cpu_ref as O
     n = rows_chunks * BATCH
     p = O.make_params(G, H, DEPTH, seed=1)
@@ -189,23 +208,23 @@ def cpu_baseline(rows_chunks=8, steps=12):
         tdt += (time.perf_counter() - t0) if i else 0.0
     return {"value": round(n / (1000 * dt), 3), "unit": "spots/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{steps} reverse steps of {n} spots x {G} genes (hidden {H}, chunks of {BATCH}), "
-                      f"{dt:.2f} s/step, extrapolated to 1000 steps",
+                      f"{dt:.2f} s/step, extrapolated to 1000 steps of the full matrix",
             "train_cells_per_s": round(BATCH * tsteps / tdt, 1),
             "train_sample": f"{tsteps} training iterations of {BATCH} cells (forward, masked MSE, backward, clip, AdamW)"}
 
 
-def train_throughput(dtype, dev, steps=20, warmup=5, dist=None, rank=0, world=1):
+def train_throughput(dtype, dev, g=G, h=H, steps=20, warmup=5, dist=None, rank=0, world=1):
     """train cells/s = cells through one full iteration (add-noise, forward, masked MSE, backward,
-    clip, AdamW, operand repack) per second, steady state, reference batch of 512 cells PER RANK at the cfg2 model.
+    clip, AdamW, operand repack) per second, steady state, reference batch of 512 cells PER RANK.
     With a process group (world > 1) this is data-parallel training: every rank steps on its own batch,
     the flat gradient is all-reduced in depth+2 buckets issued between the backward segments, and the time is the
     max over ranks; cells/s counts the cells of all ranks."""
     from stdiff_amd import synth as O
     from stdiff_amd.train_engine import TrainEngine
-    model = build_model(dtype, dev)
-    eng = TrainEngine(model, lr=1e-4, diffusion_step=T, mask=O.kfold_mask(G, 0))
+    model = build_model(dtype, dev, g, h)
+    eng = TrainEngine(model, lr=1e-4, diffusion_step=T, mask=O.kfold_mask(g, 0))
     assert eng.world == world
-    st = torch.from_numpy(O.synth_expression(8 * BATCH, G, 1 + rank) * 2 - 1).to(dev)
+    st = torch.from_numpy(O.synth_expression(8 * BATCH, g, 1 + rank) * 2 - 1).to(dev)
     graph = world == 1                     # one hipGraph per iteration (parallel dW branches); DDP steps are eager
     for i in range(warmup):
         eng.step(st[:BATCH], st[:BATCH], use_graph=graph)
@@ -224,30 +243,57 @@ def train_throughput(dtype, dev, steps=20, warmup=5, dist=None, rank=0, world=1)
         dt = float(tmax.item())
     loss = float(eng.loss)
     assert loss == loss, "non-finite training loss"
-    return {"cells_per_s": round(world * BATCH / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch_per_rank": BATCH,
-            "ranks": world, "dtype": dtype, "grad_allreduce_MB": round(eng.total * 4 / 1e6, 1) if world > 1 else 0,
-            "tflops": round(world * 3 * BATCH * (6 * G * H + 512 * H + 222 * H * H + 24 * BATCH * H) / dt / 1e12, 1)}
+    out = {"cells_per_s": round(world * BATCH / dt, 1), "ms_per_step": round(dt * 1e3, 3), "batch_per_rank": BATCH,
+           "ranks": world, "dtype": dtype, "genes": g, "hidden": h,
+           "grad_allreduce_MB": round(eng.total * 4 / 1e6, 1) if world > 1 else 0,
+           "tflops": round(world * 3 * BATCH * (6 * g * h + 512 * h + 222 * h * h + 24 * BATCH * h) / dt / 1e12, 1)}
+    del eng, model
+    torch.cuda.empty_cache()
+    return out
+
+
+def launch_ranks(n, argv):
+    """--gpus N > 1 outside a launcher: start the N ranks as children (this process has made no GPU call), relay their
+    output (inherited stdout / stderr: rank 0 prints the JSON line) and return their exit status."""
+    rehearsal = os.environ.get("STDIFF_BENCH_REHEARSAL") == "1"
+    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if have < n and not rehearsal:
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible (STDIFF_BENCH_REHEARSAL=1 runs the N-rank "
+              f"plumbing on one GPU over gloo; its numbers mean nothing)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.run(cmd).returncode
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32"],
-                    help="MFMA operand format (fp32 accumulation and residual stream in all three).  fp16 is the "
-                         "default: it is the 16-bit format whose per-call error (5e-4) meets the 1e-3 tolerance; "
-                         "bf16 (4e-3) is timed next to it")
-    ap.add_argument("--rows", type=int, default=20000, help="spots per GPU")
+                    help="MFMA operand format of the headline (fp32 accumulation and residual stream in all three). "
+                         "fp16 is the default: the 16-bit format whose per-call error (5e-4) meets the 1e-3 "
+                         "tolerance; bf16 (4e-3) and fp32 (1e-6) are timed next to it in the same line")
+    ap.add_argument("--spots", type=int, default=SPOTS, help="total spots over all GPUs (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary metric (train cells/s)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the bf16 / fp32 legs of the sampling metric")
     ap.add_argument("--lanes", type=int, default=0, help="concurrent chunk groups per GPU (0 = engine default)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
     dist = None
     # STDIFF_BENCH_REHEARSAL=1: run the N-rank plumbing (launcher env, barriers, max-over-ranks, rank-0 line) on a box
     # with ONE GPU: every rank uses cuda:0 and the process group is gloo.  Numbers from such a run mean nothing.
@@ -269,16 +315,18 @@ def main():
     from stdiff_amd import synth as O         # synthetic inputs (the oracle is imported by cpu_baseline() only)
     from stdiff_amd import engine as E
     from stdiff_amd.model.stDiff_scheduler import NoiseScheduler
+    from stdiff_amd.parallel import shard_chunks
 
     model = build_model(args.dtype, dev)
     train_dtype = "bf16" if args.dtype == "fp16" else args.dtype     # fp16 is a sampling format; training stays bf16
     eng = model.engine()
-    R = args.rows
-    lens = [min(BATCH, R - i) for i in range(0, R, BATCH)]
+    all_lens = [min(BATCH, args.spots - i) for i in range(0, args.spots, BATCH)]
+    lo, hi, lens = shard_chunks(all_lens, rank, world)               # this rank's contiguous run of chunks
+    R = hi - lo
     mask_np = O.kfold_mask(G, 0)
-    st = O.synth_expression(R, G, seed=1 + rank)
-    gt = torch.from_numpy((st * mask_np) * 2 - 1).to(dev)
     mask = torch.from_numpy(mask_np).to(dev)
+    gt = O.synth_expression_device(R, G, 1 + rank, dev)
+    gt.mul_(mask).mul_(2).sub_(1)                                    # (st * mask) * 2 - 1   (test-stDiff.py:98-108)
     sched = NoiseScheduler(T, beta_schedule="cosine")
 
     def barrier():
@@ -288,7 +336,7 @@ def main():
             torch.cuda.synchronize()
 
     with torch.no_grad():
-        smp = E.LanedSampler(eng, sched, lens, gt, gt, mask, seed=1234, row_offset=rank * R,
+        smp = E.LanedSampler(eng, sched, lens, gt, gt, mask, seed=1234, row_offset=lo,
                              use_graph=not args.no_graph, lanes=args.lanes or None)
         smp.init()
         ts = list(range(T))[::-1]
@@ -314,58 +362,76 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    assert bool(torch.isfinite(smp.x).all()), "non-finite sample state"
+    assert bool(torch.isfinite(smp.x[:8192]).all()) and bool(torch.isfinite(smp.x[-8192:]).all()), "non-finite sample state"
     ms_per_step = dt / args.steps * 1e3
-    value = world * R / (T * ms_per_step * 1e-3)
-    step_flops = sum(n * flops_per_row(n) for n in lens)
+    value = args.spots / (T * ms_per_step * 1e-3)
+    step_flops = sum(n * flops_per_row(n) for n in all_lens)         # whole job, all ranks
+    slabs = smp.parts[0].slabs
+    lanes = len(smp.parts)
 
+    which = "BASELINE configs[3]" if (args.spots, G, H) == (SPOTS, 1024, 1024) else "configs[3] model at a reduced spot count"
     rec = {
         "metric": "imputed spots/sec (1000-step DDPM sampling)", "value": round(value, 2), "unit": "spots/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype,
         "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU, not a measurement)",
-        "config": {"workload": f"BASELINE configs[1]: {R} spots x {G} genes per GPU, hidden {H}, depth {DEPTH}, "
-                               f"{HEADS} heads, chunks of {BATCH}, cosine T={T}; value = spots / (1000 x measured "
-                               f"seconds per reverse step)", "parallelism": f"spot-sharded x{world}, no collective",
-                   "hipgraph": not args.no_graph, "noise": "in-kernel Philox4x32-10",
-                   "lanes_per_gpu": len(smp.parts)},
+        "config": {"workload": f"{which}: {args.spots} spots x {G} genes in total, sharded chunk-aligned over "
+                               f"{world} GPU(s) ({R} spots on rank 0), hidden {H}, depth {DEPTH}, {HEADS} heads, "
+                               f"chunks of {BATCH}, cosine T={T}; value = spots / (1000 x measured seconds per "
+                               f"reverse step, max over ranks)",
+                   "parallelism": f"spot-sharded x{world}, no collective", "hipgraph": not args.no_graph,
+                   "noise": "in-kernel Philox4x32-10", "lanes_per_gpu": lanes,
+                   "row_slabs_per_lane": len(slabs), "rows_per_slab": slabs[0][1] - slabs[0][0]},
         "step_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12, 1),
     }
     if rank == 0:
+        ws = max((sl[2] for sl in slabs), key=lambda w: w.R)         # a full slab's buffers (idle now)
         with torch.no_grad():
-            rec["roofline"] = measure_gemm_roofline(eng, eng.workspace(lens, lane=99), args.dtype)
-        rec["roofline"]["whole_step_frac"] = round(rec["step_tflops"] / PEAK[args.dtype], 4)
+            rec["roofline"] = measure_gemm_roofline(eng, ws, args.dtype)
+        rec["roofline"]["whole_step_frac"] = round(rec["step_tflops"] / world / PEAK[args.dtype], 4)
         with torch.no_grad():
-            rec["hbm_kernels"] = measure_hbm_kernels(eng, eng.workspace(lens, lane=99), sched, gt, mask, args.dtype)
-        if world == 1 and not args.no_train:
-            lanes = len(smp.parts)
-            del smp
+            rec["hbm_kernels"] = measure_hbm_kernels(eng, ws, sched, gt, mask, args.dtype)
+    del smp
+    eng._ws.clear()
+    torch.cuda.empty_cache()
+    if world == 1:
+        if not args.no_alt and not args.no_graph:
+            for alt, st_, wu in (("bf16", 5, 1), ("fp32", 2, 0)):
+                if alt != args.dtype:
+                    rec[alt + "_operands"] = alt_sampling_leg(alt, dev, lens, gt, mask, sched, lo, args.spots, lanes, st_, wu)
+        if not args.no_train:
+            del gt
             torch.cuda.empty_cache()
             rec["train"] = train_throughput(train_dtype, dev)
-            if args.dtype == "fp16" and not args.no_graph:      # after the training leg: tools/roofline_check.py
-                torch.cuda.empty_cache()                        # takes the GEMM launches before it as the roofline ones
-                rec["bf16_operands"] = alt_sampling_leg("bf16", dev, lens, gt, mask, sched, rank, R, lanes)
-        if world == 1 and not args.no_cpu_baseline:
+            # the data-parallel configuration's per-rank shape (BASELINE configs[2]: 2000 genes, hidden 2048)
+            rec["train_cfg2_shape"] = train_throughput(train_dtype, dev, g=2000, h=2048, steps=10, warmup=3)
+        if not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
+    failed = False
     if world > 1 and not args.no_train:
         # secondary metric on N ranks: data-parallel training.  A watchdog on every rank guarantees that rank 0 still
-        # prints its line (without this leg) should a collective ever stall: the headline number is already measured.
+        # prints its line should a collective ever stall -- with the leg marked failed and a NON-ZERO exit status.
         import threading
         done = threading.Event()
+        limit = int(os.environ.get("STDIFF_BENCH_TRAIN_TIMEOUT", "180"))
 
         def watchdog():
-            if not done.wait(120):
+            if not done.wait(limit):
                 if rank == 0:
-                    rec["train"] = {"error": "data-parallel training leg did not finish within 120 s"}
+                    rec["train"] = {"error": f"data-parallel training leg did not finish within {limit} s", "failed": True}
                     print(json.dumps(rec), flush=True)
-                os._exit(0)
+                os._exit(3)
         threading.Thread(target=watchdog, daemon=True).start()
         dist.barrier()                    # rank 0 measured its roofline meanwhile
         try:
+            # BASELINE configs[2] shape (2000 genes, hidden 2048: 1.9 GB of gradients per step); the rehearsal moves
+            # them through the host (gloo), so it steps the configs[3] model (0.48 GB) a few times only
             tr = train_throughput(train_dtype, dev, dist=dist, rank=rank, world=world,
-                                  **({"steps": 2, "warmup": 1} if rehearsal else {}))   # gloo moves 480 MB through the host
-        except Exception as e:            # noqa: BLE001 -- reported in the line
-            tr = {"error": repr(e)}
+                                  **({"steps": 2, "warmup": 1} if rehearsal else
+                                     {"g": 2000, "h": 2048, "steps": 10, "warmup": 3}))
+        except Exception as e:            # noqa: BLE001 -- reported in the line, and in the exit status
+            tr = {"error": repr(e), "failed": True}
+            failed = True
         done.set()
         if rank == 0:
             rec["train"] = tr
@@ -374,6 +440,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define STDIFF_ABI_VERSION 4
+#define STDIFF_ABI_VERSION 5
 
 enum { STDIFF_F32 = 0, STDIFF_BF16 = 1 };
 
@@ -144,8 +144,10 @@ int stdiff_preprocess_rows(const float* x, int ldx, float* y, int ldy, int R, in
  * reconstruct_x0 :68-78, q_posterior :80-90, get_variance :92-100; splice model/sample.py:94-95):
  *   x0 = clamp(a*x - b*eps, -1, 1)   (pred_type 0 'noise')   |   x0 = eps   (pred_type 1 'x_start')
  *   x  = (c1*x0 + c2*x + sigma*z) * (1-mask) + mask*gt       with (a,b,c1,c2,sigma) = coef[t*5 .. t*5+4]
- * t = *t_dev (device int32, so a captured graph can be replayed) ; z = z_base + z_index*R*G when z_base != NULL
- * (z_index = t_first - t), otherwise Philox4x32-10 + Box-Muller keyed by (seed, t, global element index).
+ * t = *t_dev (device int32, so a captured graph can be replayed) ; z = z_base + z_index*z_rows*G when z_base != NULL
+ * (z_index = t_first - t; z_rows = rows of one step's noise matrix, 0 = R: a call that updates a row slab of a larger
+ * sample passes the slab's first row of step 0 as z_base and the whole sample's row count as z_rows), otherwise
+ * Philox4x32-10 + Box-Muller keyed by (seed, t, global element index).
  * Also refreshes xp (the [R,Gp] MFMA operand copy of x) when xp != NULL. Arithmetic order equals the reference's
  * (no FMA contraction) so fp32 results are bit-identical to it. */
 typedef struct {
@@ -154,6 +156,7 @@ typedef struct {
     const float* z_base; uint64_t seed; int64_t row_offset;   /* row_offset: global index of row 0 (sharded sampling) */
     void* xp; int ldxp; int xp_dtype;
     int R, G, pred_type;
+    int64_t z_rows;
 } stdiff_step_args;
 int stdiff_ddpm_step(const stdiff_step_args* a, void* stream);
 /* *t_dev -= 1 (one thread; closes a captured reverse step). */

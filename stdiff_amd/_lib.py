@@ -37,7 +37,7 @@ class StepArgs(C.Structure):
                 ("t_dev", vp), ("t_first", i32),
                 ("z_base", vp), ("seed", u64), ("row_offset", i64),
                 ("xp", vp), ("ldxp", i32), ("xp_dtype", i32),
-                ("R", i32), ("G", i32), ("pred_type", i32)]
+                ("R", i32), ("G", i32), ("pred_type", i32), ("z_rows", i64)]
 
 
 class BlockWeights(C.Structure):
@@ -122,7 +122,7 @@ def lib(fp16=False):
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.stdiff_abi_version() != 4:
+        if L.stdiff_abi_version() != 5:
             raise RuntimeError(f"{base} ABI version mismatch")
         if L.stdiff_h16_format() != int(bool(fp16)):
             raise RuntimeError(f"{base} was built with the wrong 16-bit operand format")

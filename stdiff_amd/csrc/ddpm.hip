@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(stdiff_step_args a) {
                 sg = a.coef[t * 5 + 4];
     const int gq = (a.G + 3) >> 2;
     const size_t total = (size_t)a.R * gq;
-    const float* zb = a.z_base ? a.z_base + (size_t)(a.t_first - t) * a.R * a.G : nullptr;
+    const float* zb = a.z_base ? a.z_base + (size_t)(a.t_first - t) * (size_t)(a.z_rows > 0 ? a.z_rows : a.R) * a.G : nullptr;
     const bool pvec = VEC && (a.ldxp % 4 == 0);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int r = (int)(i / gq), cg = (int)(i % gq), c = cg * 4;
@@ -211,6 +211,7 @@ extern "C" int stdiff_ddpm_step(const stdiff_step_args* a, void* stream) {
     STDIFF_CHECK_ARG(a && a->x && a->eps && a->gt && a->mask && a->coef && a->t_dev);
     STDIFF_CHECK_ARG(a->R >= 0 && a->G > 0 && (a->pred_type == 0 || a->pred_type == 1));
     STDIFF_CHECK_ARG(!a->xp || a->ldxp >= a->G);
+    STDIFF_CHECK_ARG(a->z_rows == 0 || a->z_rows >= a->R);
     if (a->R == 0) return STDIFF_OK;
     const bool vec = a->G % 4 == 0 && al16(a->x) && al16(a->eps) && al16(a->gt) && al16(a->mask) && al16(a->z_base) &&
                      al16(a->xp);

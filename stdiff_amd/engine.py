@@ -94,24 +94,34 @@ class PackedWeights:
 
 
 class Workspace:
-    """Activation buffers for R rows in chunks (chunk = one reference mini-batch; attention never crosses chunks)."""
+    """Activation buffers for R rows in chunks (chunk = one reference mini-batch; attention never crosses chunks).
 
-    def __init__(self, pw, chunk_lens):
+    `share`: another Workspace with at least as many rows whose buffers this one aliases (row slabs of one sampler
+    run one after the other on one stream, so they use the same memory; only the chunk offsets differ)."""
+
+    BUFS = (("h", 1, True), ("s", 1, False), ("mod", 6, False), ("xn", 1, False), ("qkv", 3, False), ("o", 1, False),
+            ("u", 4, False), ("fmod", 2, False))                 # name, width / H, fp32?
+
+    def __init__(self, pw, chunk_lens, share=None):
         R = int(sum(chunk_lens))
         H, dev, tdt = pw.H, pw.device, pw.tdt
+        if R * 6 * H * (4 if pw.dtype == F32 else 2) >= 2 ** 31:
+            raise ValueError(f"{R} rows in one workspace: the kernels index activations with 32-bit byte offsets "
+                             f"(use row slabs: engine.plan_slabs)")
         self.R, self.chunk_lens = R, list(chunk_lens)
         cu = np.concatenate([[0], np.cumsum(chunk_lens)]).astype(np.int32)
         self.cu_rows = torch.from_numpy(cu).to(dev)
-        self.h = torch.empty((R, H), device=dev, dtype=torch.float32)
-        self.s = torch.empty((R, H), device=dev, dtype=tdt)
-        self.mod = torch.empty((R, 6 * H), device=dev, dtype=tdt)
-        self.xn = torch.empty((R, H), device=dev, dtype=tdt)
-        self.qkv = torch.empty((R, 3 * H), device=dev, dtype=tdt)
-        self.o = torch.empty((R, H), device=dev, dtype=tdt)
-        self.u = torch.empty((R, 4 * H), device=dev, dtype=tdt)
-        self.fmod = torch.empty((R, 2 * H), device=dev, dtype=tdt)
-        self.xp = torch.zeros((R, pw.Gp), device=dev, dtype=tdt)       # pad columns stay zero
-        self.eps = torch.empty((R, pw.G), device=dev, dtype=torch.float32)
+        if share is not None:
+            assert share.R >= R
+        for name, width, f32 in self.BUFS:
+            if share is not None:
+                buf = getattr(share, name)[:R]
+            else:
+                buf = torch.empty((R, width * H), device=dev, dtype=torch.float32 if f32 else tdt)
+            setattr(self, name, buf)
+        self.eps = share.eps[:R] if share is not None else torch.empty((R, pw.G), device=dev, dtype=torch.float32)
+        self._xp = None
+        self._pw = pw
         s = L.DitWorkspace()
         s.R, s.n_chunks, s.max_chunk_rows = R, len(chunk_lens), int(max(chunk_lens)) if chunk_lens else 0
         s.cu_rows = ptr(self.cu_rows)
@@ -119,22 +129,66 @@ class Workspace:
             setattr(s, n, ptr(getattr(self, n)))
         self.struct = s
 
+    @property
+    def xp(self):
+        """Packed [R, Gp] operand copy of the input (pad columns stay zero); made on first use -- the reverse sampler
+        keeps its own full-length copy instead."""
+        if self._xp is None:
+            self._xp = torch.zeros((self.R, self._pw.Gp), device=self._pw.device, dtype=self._pw.tdt)
+        return self._xp
+
+
+def slab_rows_limit(pw):
+    """Most rows one launch may cover: every activation matrix ([R, 6H] the widest) stays below 2^31 bytes, so the
+    kernels' 32-bit byte offsets (LDS-DMA buffer descriptors) are exact.  STDIFF_SLAB_ROWS lowers it."""
+    limit = (2 ** 31 - 2 ** 20) // (6 * pw.H * (4 if pw.dtype == F32 else 2))
+    want = int(os.environ.get("STDIFF_SLAB_ROWS", "65536"))
+    return max(1, min(limit, want))
+
+
+def plan_slabs(chunk_lens, max_rows):
+    """Cut a run of chunks into slabs of whole chunks with at most `max_rows` rows each (a chunk longer than that is a
+    slab of its own): [(row_lo, row_hi, chunk_lens_of_the_slab)].  Slabs of a sampler are processed one after the other
+    through ONE set of activation buffers: the working set stays a few GB however many spots a GPU holds."""
+    out, cur, r0, r = [], [], 0, 0
+    for c in chunk_lens:
+        c = int(c)
+        if cur and r - r0 + c > max_rows:
+            out.append((r0, r, cur))
+            cur, r0 = [], r
+        cur.append(c)
+        r += c
+    if cur:
+        out.append((r0, r, cur))
+    return out
+
 
 class DenoiserEngine:
     def __init__(self, pw):
         self.pw = pw
         self._ws = {}
 
-    def workspace(self, chunk_lens, lane=0):
+    def workspace(self, chunk_lens, lane=0, share=None):
         """Cached activation buffers for this chunking; `lane` separates concurrent users of equal chunkings."""
         lens = tuple(int(c) for c in chunk_lens)
-        key = (lens, int(lane))
+        key = (lens, int(lane), id(share) if share is not None else 0)
         ws = self._ws.get(key)
         if ws is None:
             if len(self._ws) > 8:
                 self._ws.clear()
-            ws = self._ws[key] = Workspace(self.pw, lens)
+            ws = self._ws[key] = Workspace(self.pw, lens, share=share)
         return ws
+
+    def slab_workspaces(self, chunk_lens, lane=0):
+        """[(row_lo, row_hi, Workspace)] for the slabs of `chunk_lens` (plan_slabs): the largest slab owns the buffers,
+        the others alias them."""
+        slabs = plan_slabs(chunk_lens, slab_rows_limit(self.pw))
+        if not slabs:
+            return []
+        big = max(slabs, key=lambda sl: sl[1] - sl[0])
+        owner = self.workspace(big[2], lane)
+        return [(lo, hi, owner if tuple(lens) == tuple(big[2]) else self.workspace(lens, lane, share=owner))
+                for lo, hi, lens in slabs]
 
     # time_emb(t)  (TimestepEmbedder.forward, stDiff_model.py:82-85) -> fp32 [R,H]
     def time_embed(self, t):
@@ -150,20 +204,25 @@ class DenoiserEngine:
         return ops.gemm(yp, pw.w["cond_layer.0.weight"], pw.b("cond_layer.0.bias"), out_dtype=torch.float32,
                         epi=L.EPI_ADD if temb is not None else L.EPI_BIAS, res=temb)
 
-    def run(self, ws):
-        """eps = blocks/final(in_layer(ws.xp); ws.s)   (stDiff_model.py:240-243)."""
-        check(lib_for(ws.xp).stdiff_dit_forward(C.byref(self.pw.struct), C.byref(ws.struct), ptr(ws.xp), ptr(ws.s),
+    def run(self, ws, xp=None, s=None):
+        """eps = blocks/final(in_layer(xp); s)   (stDiff_model.py:240-243); xp / s default to the workspace's own."""
+        xp = ws.xp if xp is None else xp
+        s = ws.s if s is None else s
+        assert xp.shape == (ws.R, self.pw.Gp) and xp.is_contiguous() and s.shape == (ws.R, self.pw.H)
+        check(lib_for(xp).stdiff_dit_forward(C.byref(self.pw.struct), C.byref(ws.struct), ptr(xp), ptr(s),
                                        ptr(ws.eps), ws.eps.stride(0), stream()))
         return ws.eps
 
     def forward(self, x, t, y, chunk_lens=None):
         """DiT_stDiff.forward(x, t, y) (stDiff_model.py:231-243) for inference; returns a fresh fp32 [R,G]."""
         R = x.shape[0]
-        ws = self.workspace(chunk_lens or [R])
-        ops.pack_rows(x, self.pw.Gp, self.pw.tdt, out=ws.xp)
-        c = self.cond_embed(y, self.time_embed(t))
-        ops.silu_cond(c, out=ws.s)
-        return self.run(ws).clone()
+        out = torch.empty((R, self.pw.G), device=self.pw.device, dtype=torch.float32)
+        for lo, hi, ws in self.slab_workspaces(chunk_lens or [R]):
+            ops.pack_rows(x[lo:hi], self.pw.Gp, self.pw.tdt, out=ws.xp)
+            c = self.cond_embed(y[lo:hi], self.time_embed(t[lo:hi]))
+            ops.silu_cond(c, out=ws.s)
+            out[lo:hi].copy_(self.run(ws))
+        return out
 
 
 def step_coefficients(sched):
@@ -190,7 +249,10 @@ class ReverseSampler:
             raise NotImplementedError()                                  # stDiff_scheduler.py:125-126
         pw = engine.pw
         self.engine, self.pw = engine, pw
-        self.ws = engine.workspace(chunk_lens, lane)
+        # row slabs (plan_slabs): the denoiser runs slab after slab through one set of activation buffers; what is
+        # kept for every row is x, its packed operand copy xp, gt and the projected condition
+        self.slabs = engine.slab_workspaces(chunk_lens, lane)
+        self.R = int(sum(chunk_lens))
         self.T = len(sched)
         self.gt, self.mask = gt, mask
         self.pred_type = 0 if pred_type == "noise" else 1
@@ -198,34 +260,46 @@ class ReverseSampler:
         dev = pw.device
         self.coef = step_coefficients(sched).to(dev)
         self.temb = engine.time_embed(torch.arange(self.T, device=dev, dtype=torch.int64))     # [T,H]
-        self.ycond = engine.cond_embed(x_cond)                                                 # [R,H]
-        self.x = x_out if x_out is not None else torch.empty((self.ws.R, pw.G), device=dev, dtype=torch.float32)
-        assert self.x.shape == (self.ws.R, pw.G) and self.x.is_contiguous() and self.x.dtype == torch.float32
+        self.ycond = torch.empty((self.R, pw.H), device=dev, dtype=torch.float32)              # [R,H]
+        for lo, hi, _ in self.slabs:
+            self.ycond[lo:hi].copy_(engine.cond_embed(x_cond[lo:hi]))
+        self.xp = torch.zeros((self.R, pw.Gp), device=dev, dtype=pw.tdt)                       # pad columns stay zero
+        self.x = x_out if x_out is not None else torch.empty((self.R, pw.G), device=dev, dtype=torch.float32)
+        assert self.x.shape == (self.R, pw.G) and self.x.is_contiguous() and self.x.dtype == torch.float32
         self.t_dev = torch.zeros((1,), device=dev, dtype=torch.int32)
         self.graph = None
         self._graph_z = None
         self.stream = None
 
     def init(self, x_T=None):
-        ops.init_sample(self.x, self.gt, self.mask, z=x_T, seed=self.seed, row_offset=self.row_offset, xp=self.ws.xp)
+        for lo, hi, _ in self.slabs:
+            ops.init_sample(self.x[lo:hi], self.gt[lo:hi], self.mask, z=None if x_T is None else x_T[lo:hi],
+                            seed=self.seed, row_offset=self.row_offset + lo, xp=self.xp[lo:hi])
+
+    def _denoise_slab(self, lo, hi, ws):
+        ops.silu_cond(self.ycond[lo:hi], temb=self.temb, t_index=self.t_dev, out=ws.s)
+        return self.engine.run(ws, xp=self.xp[lo:hi])
 
     def _enqueue_step(self, t_first, z_base):
-        ws = self.ws
-        ops.silu_cond(self.ycond, temb=self.temb, t_index=self.t_dev, out=ws.s)
-        self.engine.run(ws)
-        ops.ddpm_step(self.x, ws.eps, self.gt, self.mask, self.coef, self.t_dev, t_first, z_base=z_base,
-                      seed=self.seed, row_offset=self.row_offset, xp=ws.xp, pred_type=self.pred_type)
+        for lo, hi, ws in self.slabs:
+            eps = self._denoise_slab(lo, hi, ws)
+            ops.ddpm_step(self.x[lo:hi], eps, self.gt[lo:hi], self.mask, self.coef, self.t_dev, t_first,
+                          z_base=None if z_base is None else z_base[0, lo:hi], z_rows=self.R,
+                          seed=self.seed, row_offset=self.row_offset + lo, xp=self.xp[lo:hi], pred_type=self.pred_type)
         ops.advance_timestep(self.t_dev)
 
     def denoise_only(self, t):
-        """eps for the current x at timestep t (teacher-forced parity checks)."""
+        """eps [R,G] for the current x at timestep t (teacher-forced parity checks)."""
         self.t_dev.fill_(int(t))
-        ops.silu_cond(self.ycond, temb=self.temb, t_index=self.t_dev, out=self.ws.s)
-        return self.engine.run(self.ws)
+        out = torch.empty((self.R, self.pw.G), device=self.pw.device, dtype=torch.float32)
+        for lo, hi, ws in self.slabs:
+            out[lo:hi].copy_(self._denoise_slab(lo, hi, ws))
+        return out
 
     def set_x(self, x):
         self.x.copy_(x)
-        ops.pack_rows(self.x, self.pw.Gp, self.pw.tdt, out=self.ws.xp)
+        for lo, hi, _ in self.slabs:
+            ops.pack_rows(self.x[lo:hi], self.pw.Gp, self.pw.tdt, out=self.xp[lo:hi])
 
     def run(self, timesteps, z=None):
         """timesteps: descending consecutive list (sample.py:57,63-64); z: optional injected noise [len-ish,R,G]
@@ -353,7 +427,7 @@ class LanedSampler:
                                              row_offset=row_offset + r0, seed=seed, use_graph=use_graph, lane=i,
                                              x_out=self.x[r0:r1]))
             c0, r0 = c0 + n, r1
-        self.bounds = [(p.row_offset - row_offset, p.row_offset - row_offset + p.ws.R) for p in self.parts]
+        self.bounds = [(p.row_offset - row_offset, p.row_offset - row_offset + p.R) for p in self.parts]
         self.use_graph = use_graph
         if use_graph and len(self.parts) > 1:           # lane streams that really overlap (see concurrent_streams)
             for p, st in zip(self.parts, concurrent_streams(engine.pw.device, len(self.parts))):

@@ -29,7 +29,6 @@ def model_sample_stDiff(model, device, dataloader, total_sample, time, is_condi,
         raise ValueError("is_condi=False passes y=None to cond_layer, which the reference cannot run either")
     x_cond, lens = _collect_condition(dataloader, device)
     eng = model.engine()
-    ws = eng.workspace(lens)
     t = torch.full((sum(lens),), int(time), dtype=torch.int64, device=eng.pw.device)
     return eng.forward(total_sample.float().to(eng.pw.device).contiguous(), t, x_cond, chunk_lens=lens)
 
@@ -59,7 +58,7 @@ def sample_stDiff(model,
     Returns a host float32 ndarray [N, G].  Keyword-only extras (not in the reference): ``x_T`` / ``step_noise``
     inject the initial draw [N,G] and the per-step draws [n_steps-ish, N, G] (row i is used at timestep
     timesteps[0]-i) for bit-reproducible parity runs; otherwise noise comes from an in-kernel Philox stream keyed
-    by ``seed`` (default torch.initial_seed()), the global row index and the timestep.  ``lanes``: concurrent chunk
+    by ``seed`` (default: drawn from torch's global generator), the global row index and the timestep.  ``lanes``: concurrent chunk
     groups on separate HIP streams (default: engine.default_lanes; results do not depend on it)."""
     if not is_condi:
         raise ValueError("is_condi=False passes y=None to cond_layer (sample.py:13-14): unsupported by the reference "
@@ -83,7 +82,9 @@ def sample_stDiff(model,
     if sample_intermediate:
         timesteps = timesteps[:sample_intermediate]
     if seed is None:
-        seed = torch.initial_seed() & 0x7FFFFFFFFFFFFFFF
+        # one draw from the global generator per call: successive calls differ (as the reference's torch.randn draws
+        # do) and torch.manual_seed still fixes the sequence
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     with torch.no_grad():
         smp = E.LanedSampler(eng, noise_scheduler, lens, x_cond, gt_t, mask_t, pred_type=model_pred_type, seed=seed,
                              use_graph=use_graph, lanes=1 if step_noise is not None else lanes)

@@ -133,7 +133,7 @@ def gather_rows2(a, b, idx, out_a=None, out_b=None):
     return out_a, out_b
 
 
-def ddpm_step(x, eps, gt, mask, coef, t_dev, t_first, z_base=None, seed=0, row_offset=0, xp=None, pred_type=0):
+def ddpm_step(x, eps, gt, mask, coef, t_dev, t_first, z_base=None, seed=0, row_offset=0, xp=None, pred_type=0, z_rows=0):
     require_gpu(x, eps, gt, mask, coef, t_dev, z_base, xp)
     a = L.StepArgs()
     a.x, a.eps, a.gt, a.mask, a.coef = ptr(x), ptr(eps), ptr(gt), ptr(mask), ptr(coef)
@@ -141,7 +141,7 @@ def ddpm_step(x, eps, gt, mask, coef, t_dev, t_first, z_base=None, seed=0, row_o
     a.z_base, a.seed, a.row_offset = ptr(z_base), seed, row_offset
     if xp is not None:
         a.xp, a.ldxp, a.xp_dtype = ptr(xp), xp.stride(0), dt_of(xp)
-    a.R, a.G, a.pred_type = x.shape[0], x.shape[1], pred_type
+    a.R, a.G, a.pred_type, a.z_rows = x.shape[0], x.shape[1], pred_type, int(z_rows)
     check(lib_for(xp).stdiff_ddpm_step(C.byref(a), stream()))
 
 

@@ -33,3 +33,26 @@ def kfold_mask(g, fold=0, n_splits=5, seed=0):
     m = np.ones((g,), dtype=np.float32)
     m[test] = 0
     return m
+
+
+def synth_expression_device(n, g, seed, device, block=65536):
+    """synth_expression drawn ON THE DEVICE (torch's Poisson sampler) for matrices too large to make on the host in
+    reasonable time (BASELINE configs[3]: 1 M spots x 1024 genes = 4 GB): the same Poisson-LogNormal model and the same
+    normalize_total -> log1p -> per-row max-abs pipeline, fp32 in [0, 1].  Input synthesis for bench.py only; the
+    values differ from the host generator's (another RNG)."""
+    import torch
+    rng = np.random.default_rng(seed)
+    lam = torch.from_numpy(rng.lognormal(0.0, 1.0, size=g).astype(np.float32)).to(device)
+    s = torch.from_numpy(rng.lognormal(0.0, 0.5, size=n).astype(np.float32)).to(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    out = torch.empty((n, g), device=device, dtype=torch.float32)
+    for i in range(0, n, block):
+        k = torch.poisson(lam[None, :] * s[i:i + block, None], generator=gen)
+        tot = k.sum(1, keepdim=True)
+        tot[tot == 0] = 1.0
+        k = torch.log1p(k / tot * 1e4)
+        mx = k.abs().amax(1, keepdim=True)
+        mx[mx == 0] = 1.0
+        out[i:i + block] = k / mx
+    return out

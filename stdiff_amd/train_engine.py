@@ -130,7 +130,14 @@ class TrainCore:
             du=z(C, 4 * H), dupre=z(C, 4 * H), do=z(C, H), dqkv=z(C, 3 * H), delta=z(C, self.heads, dt=f32),
             ds32=z(C, H, dt=f32), dc=z(C, H, dt=f32), dcT_=z(C, H), de1=z(C, H), da1=z(C, H), dhT_=z(C, H),
         )
+        if G % 8:
+            # odd gene counts: the weight-gradient GEMMs of in / cond / out layer go through transposed copies
+            # (_dW_enqueue).  Their scratch is made HERE, one pair per stream that may run such a job, so that nothing
+            # allocates while an iteration is being captured into a hipGraph (the graph keeps raw addresses).
+            a["tr"] = [(z(max(Gp, H), Cp), z(max(Gp, H), Cp)) for _ in range(2)]
         if len(self._acts) > 3:
+            # drops the CACHE entries only: captured graphs (st['a']) and autograd contexts (ctx.a) keep references
+            # to the buffer sets they recorded, so their addresses stay valid
             self._acts.clear()
         self._acts[C] = a
         return a
@@ -252,8 +259,9 @@ class TrainCore:
         m = gw.shape[0] if rows is None else rows
         if m % 8 or gw.shape[1] % 8:         # odd gene counts: 16-byte column pieces do not exist, go through copies
             Cp = a["Cp"]
-            dYT = ops.transpose(dY, rows_pad=Cp)
-            XT = ops.transpose(X, rows_pad=Cp)
+            bufY, bufX = a["tr"][1 if side else 0]
+            dYT = ops.transpose(dY, out=bufY[:dY.shape[1]], rows_pad=Cp)
+            XT = ops.transpose(X, out=bufX[:X.shape[1]], rows_pad=Cp)
             self._gemm(dYT[:m], XT[:gw.shape[1]], None, out=gw, side=side)
         else:
             self._gemm(dY, X[:, :gw.shape[1]] if X.shape[1] != gw.shape[1] else X, None, out=gw, M=m, a_kmajor=True,
@@ -360,6 +368,15 @@ class TrainEngine(TrainCore):
             # all-reduces in flight (observed: 8 x 12 MB) or with one issued behind a busy stream, so there the device
             # is synchronised and each bucket is reduced before the next is issued.
             self.async_buckets = dist.get_backend(process_group) == "nccl"
+            if self.world > 1:
+                # as torch DDP does at construction: every rank starts from rank 0's parameters (ranks that built the
+                # model under different RNG states would otherwise train different models on averaged gradients)
+                torch.cuda.synchronize(dev)
+                dist.broadcast(self.flat_p, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                               group=process_group)
+                if self.mirror is not None:
+                    self.mirror.copy_(self.flat_p)
+                self.pw.refresh()
         self.buckets = self.bucket_ranges()
         self._graphs, self._stream = {}, None
 
@@ -432,7 +449,7 @@ class TrainEngine(TrainCore):
             else:
                 st["t"].copy_(timesteps)
             if st["graph"] is None:
-                a = self.acts(C)
+                a = st["a"] = self.acts(C)          # the graph records these addresses: keep the set alive with it
                 g = ops.Graph()
                 g.begin()
                 try:
@@ -454,14 +471,21 @@ class _DitFunction(torch.autograd.Function):
         a = core.acts(C)
         ops.pack_rows(x, core.Gp, core.tdt, out=a["xp"])
         ops.pack_rows(y, core.Gp, core.tdt, out=a["yp"])
+        if a.get("in_autograd"):
+            # a forward of this batch size is still waiting for its backward: its saved activations must survive,
+            # so this call gets a buffer set of its own (which replaces the cached one)
+            core._acts.pop(C, None)
+            a = core.acts(C)
+        a["in_autograd"] = True
         eps = core.forward(a, t)
-        ctx.core, ctx.C = core, C
+        ctx.core, ctx.a = core, a
         return eps.clone()
 
     @staticmethod
     def backward(ctx, d_eps):
         core = ctx.core
-        a = core.acts(ctx.C)
+        a = ctx.a                              # the buffer set of THIS forward (cache eviction cannot swap it)
+        a["in_autograd"] = False
         ops.pack_rows(d_eps.contiguous().float(), core.Gp, core.tdt, out=a["deps"])
         core.backward(a)
         grads = tuple(core.g[n].clone() for n in core.names)

@@ -165,6 +165,38 @@ def test_train_steps_golden_fp32(golden_dir, use_graph, side, monkeypatch):
     assert torch.equal(sd["condi_emb.weight"].cpu(), p0["condi_emb.weight"])
 
 
+@pytest.mark.parametrize("G", [33, 50])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_train_odd_gene_counts_against_oracle(G, use_graph):
+    """Gene counts that are not a multiple of 8 (diffusion_impute takes any): the weight gradients of in / cond / out
+    layer go through transposed copies whose scratch is preallocated per batch size, so the iteration can be captured
+    into a hipGraph.  Two full batches and the partial last one (a second graph), each against the oracle."""
+    from stdiff_amd.train_engine import TrainEngine
+    H, depth, heads, T = 128, 2, 4, 1000
+    m, p = build(G, H, depth, heads, 40 + G, "fp32")
+    mask = O.kfold_mask(G, 0)
+    st = (O.synth_expression(168, G, 3) * 2 - 1).astype(np.float32)
+    tb = O.make_tables(T, schedule="cosine")
+    pr, state = {k: v.clone() for k, v in p.items()}, {}
+    te = TrainEngine(m, lr=1e-5, diffusion_step=T, mask=mask)      # small steps: Adam's sign-like first updates amplify
+    gen = torch.Generator().manual_seed(G)                          # rounding noise where |g| ~ 0 by at most lr
+    for lo, hi in ((0, 64), (64, 128), (128, 168), (0, 64)):
+        C = hi - lo
+        x = torch.from_numpy(st[lo:hi])
+        xc = torch.from_numpy(st[lo:hi] * mask).float()
+        noise = torch.randn(C, G, generator=gen)
+        tt = torch.randint(1, T, (C,), generator=gen)
+        loss_r, gn_r, raw = O.train_step(pr, tb, state, x, xc, noise, tt, mask, 1e-5, heads, depth)
+        loss, gn = te.step(x.to(DEV), xc.to(DEV), noise=noise.to(DEV), timesteps=tt.to(DEV), use_graph=use_graph)
+        assert abs(float(loss) - float(loss_r)) < 1e-5 * max(1.0, float(loss_r)), (lo, float(loss), float(loss_r))
+        assert abs(float(gn) - float(gn_r)) < 2e-4 * float(gn_r), (lo, float(gn), float(gn_r))
+        gscale = max(float(g.abs().max()) for g in raw.values())
+        for n in ("in_layer.0.weight", "cond_layer.0.weight", "out_layer.linear.weight", "out_layer.linear.bias"):
+            assert float((te.g[n].cpu() - raw[n]).abs().max()) < 1e-4 * gscale, (lo, n)
+    if use_graph:
+        assert len(te._graphs) == 2 and all("a" in st_ for st_ in te._graphs.values())
+
+
 def test_autograd_bridge_matches_oracle():
     """model(x,t,y) under autograd: user-side loss.backward() fills p.grad like the oracle's autograd."""
     G, H, depth, heads, C = 48, 128, 2, 4, 40
