@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define STDIFF_ABI_VERSION 5
+#define STDIFF_ABI_VERSION 6
 
 enum { STDIFF_F32 = 0, STDIFF_BF16 = 1 };
 
@@ -36,7 +36,8 @@ enum {
     STDIFF_ERR_ARG = -1,      /* null pointer / negative size / bad enum */
     STDIFF_ERR_SHAPE = -2,    /* shape not supported by the kernels (see each function) */
     STDIFF_ERR_ALIGN = -3,    /* pointer or leading dimension not 16-byte aligned */
-    STDIFF_ERR_STATE = -4     /* handle misuse (graph not captured, ...) */
+    STDIFF_ERR_STATE = -4,    /* handle misuse (graph not captured, ...) */
+    STDIFF_ERR_SCRATCH = -5   /* problem larger than the library's static scratch buffer (stdiff_gemm_static_scratch) */
 };
 
 /* GEMM epilogues: v = sum_k A[m,k] W[n,k] + bias[n] */
@@ -84,6 +85,19 @@ typedef struct {
     int a_layout, w_layout, k_valid;
 } stdiff_gemm_args;
 int stdiff_gemm(const stdiff_gemm_args* a, void* stream);
+
+/* stdiff_gemm WITHOUT ANY ALLOCATION.  No counterpart in the reference: this entry point exists for callers that cannot
+ * allocate device memory -- code under hipGraph stream capture, tight serving loops, harnesses that forbid hipMalloc --
+ * and therefore cannot supply the split-K `workspace` either.  Same arguments, same kernels and the same results as
+ * stdiff_gemm called with a workspace of STDIFF_STATIC_SCRATCH_BYTES (a->workspace / a->workspace_bytes are ignored):
+ * the fp32 partial products of a K-split go to a file-scope __device__ array inside the library (64 MiB per GPU the
+ * library runs on, held until the process ends), whose per-device address is looked up once with
+ * hipGetSymbolAddress on the first call on that device (make that first call outside stream capture).
+ * Limit: 2 * M * round_up(N, 4) * 4 bytes must fit in the buffer, else STDIFF_ERR_SCRATCH and nothing is launched.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race; calls
+ * on one stream are ordered.  Nothing in the array needs to start at zero (every slice is written before it is read). */
+#define STDIFF_STATIC_SCRATCH_BYTES (64u << 20)
+int stdiff_gemm_static_scratch(const stdiff_gemm_args* a, void* stream);
 
 /* out[c, r] = in[r, c] for r < rows, and 0 for rows <= r < rows_pad (same dtype, ld_out >= rows_pad): turns the
  * TN / NN contractions of the backward pass (dW = dY^T X, dX = dY W) into NT GEMMs with a zero-padded K. */

@@ -68,6 +68,7 @@ _SIGS = {
     "stdiff_h16_format": (i32, []),
     "stdiff_error_string": (C.c_char_p, [i32]),
     "stdiff_gemm": (i32, [C.POINTER(GemmArgs), vp]),
+    "stdiff_gemm_static_scratch": (i32, [C.POINTER(GemmArgs), vp]),
     "stdiff_transpose": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "stdiff_attention_fwd": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "stdiff_ln_modulate": (i32, [vp, i32, vp, vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, vp]),
@@ -122,7 +123,7 @@ def lib(fp16=False):
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.stdiff_abi_version() != 5:
+        if L.stdiff_abi_version() != 6:
             raise RuntimeError(f"{base} ABI version mismatch")
         if L.stdiff_h16_format() != int(bool(fp16)):
             raise RuntimeError(f"{base} was built with the wrong 16-bit operand format")
@@ -148,7 +149,7 @@ class StdiffError(RuntimeError):
 def check(rc):
     if rc != 0:
         msg = lib().stdiff_error_string(rc).decode()
-        if rc in (-1, -2, -3):
+        if rc in (-1, -2, -3, -5):
             raise ValueError(f"stdiff_hip: {msg} (status {rc})")
         raise StdiffError(f"stdiff_hip: {msg} (status {rc})")
 

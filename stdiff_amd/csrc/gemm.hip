@@ -1065,7 +1065,55 @@ inline bool al8(const void* p) { return ((uintptr_t)p & 7) == 0; }
 
 }  // namespace
 
+// Split-K scratch that is part of the LIBRARY IMAGE instead of a caller allocation (stdiff_gemm_static_scratch): one
+// copy per GPU the code object is loaded on, held until the process ends.  In host code the array's name is only a
+// stand-in for the symbol; its device address comes from hipGetSymbolAddress, per device.
+static __device__ __align__(256) float scratch[STDIFF_STATIC_SCRATCH_BYTES / sizeof(float)];
+
+namespace {
+int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long long workspace_bytes);
+
+constexpr int MAX_DEVICES = 64;
+void* g_scratch_ptr[MAX_DEVICES];          // device address of `scratch` on each GPU (0 = not looked up yet)
+
+// device address of this GPU's copy of `scratch`; looked up once per device with that device current
+int static_scratch(void** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= MAX_DEVICES) return STDIFF_ERR_ARG;
+    void* p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+    if (!p) {
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return (int)e;
+        if (!p) return STDIFF_ERR_STATE;
+        __atomic_store_n(&g_scratch_ptr[dev], p, __ATOMIC_RELEASE);      // every thread finds the same address
+    }
+    *out = p;
+    return STDIFF_OK;
+}
+}  // namespace
+
 extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
+    STDIFF_CHECK_ARG(a != nullptr);
+    return gemm_impl(a, stream, a->workspace, a->workspace_bytes);
+}
+
+// stdiff_gemm for callers that cannot allocate: the split-K partial products go to the library's own static device
+// array.  No hipMalloc / hipFree / allocating routine is called, here or below.
+extern "C" int stdiff_gemm_static_scratch(const stdiff_gemm_args* a, void* stream) {
+    STDIFF_CHECK_ARG(a != nullptr && a->M >= 0 && a->N >= 0);
+    // two K-slices of the [M, N] fp32 partial product must fit: that is the least a split needs
+    const long long per = (long long)a->M * ((a->N + 3) & ~3) * 4;
+    if (2 * per > (long long)STDIFF_STATIC_SCRATCH_BYTES) return STDIFF_ERR_SCRATCH;
+    void* ws = nullptr;
+    const int rc = static_scratch(&ws);
+    if (rc != STDIFF_OK) return rc;
+    return gemm_impl(a, stream, ws, (long long)STDIFF_STATIC_SCRATCH_BYTES);
+}
+
+namespace {
+int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long long workspace_bytes) {
     STDIFF_CHECK_ARG(a && a->M >= 0 && a->N >= 0 && a->K > 0);
     if (a->M == 0 || a->N == 0) return STDIFF_OK;          // an empty shard: nothing to do (pointers may be null)
     STDIFF_CHECK_ARG(a->A && a->W && a->C);
@@ -1130,7 +1178,7 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
     p.tiles_m = cdiv(a->M, tile == 1 ? BM : 256);
     p.tiles_n = cdiv(a->N, tile == 1 ? BN : 256);
     p.ksplit = 1; p.nk_per = a->K / bk; p.ws = nullptr; p.ldws = 0;
-    if (tile == 1 && a->workspace && ((uintptr_t)a->workspace & 15) == 0) {
+    if (tile == 1 && workspace && ((uintptr_t)workspace & 15) == 0) {
         // few tiles x long K (batch-sized training GEMMs): one block per tile would walk K alone on a mostly idle chip
         const long tiles = (long)p.tiles_m * p.tiles_n;
         const int nk = a->K / bk, ldws = (a->N + 3) & ~3;
@@ -1141,11 +1189,11 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
         static const int sblocks = [] { const char* e = getenv("STDIFF_SPLITK_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : cu_count(); }();
         int S = (int)fmin(fmin((double)smax, nk / 4.0), (double)sblocks / tiles);
         const long long per = (long long)a->M * ldws * 4;
-        if (S > 1 && per * S > a->workspace_bytes) S = (int)(a->workspace_bytes / per);
+        if (S > 1 && per * S > workspace_bytes) S = (int)(workspace_bytes / per);
         if (S > 1) {
             p.nk_per = cdiv(nk, S);
             p.ksplit = cdiv(nk, p.nk_per);
-            p.ws = (float*)a->workspace; p.ldws = ldws;
+            p.ws = (float*)workspace; p.ldws = ldws;
         }
     }
     dim3 grid(p.tiles_m * p.tiles_n * p.ksplit), block(tile == 1 ? NT : 512);
@@ -1189,6 +1237,7 @@ extern "C" int stdiff_gemm(const stdiff_gemm_args* a, void* stream) {
     STDIFF_LAUNCH_STATUS();
     return STDIFF_OK;
 }
+}  // namespace
 
 #ifdef STDIFF_GEMM_STAMPS
 extern "C" int stdiff_debug_gemm_stamps(unsigned long long* host_out) {

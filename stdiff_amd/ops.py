@@ -13,9 +13,11 @@ def round_up(a, b):
 
 
 def gemm(A, W, bias=None, out=None, out_dtype=None, epi=L.EPI_BIAS, gate=None, res=None, out2=None, M=None,
-         workspace=None, a_kmajor=False, w_kmajor=False):
+         workspace=None, a_kmajor=False, w_kmajor=False, static_scratch=False):
     """out[M,N] = epi(A[M,K] @ W[N,K]^T + bias). A/W: same dtype (fp32 or bf16), K-contiguous rows -- or, with
-    a_kmajor / w_kmajor, given as [K, M] / [K, N] (K rows; need not be a multiple of the K-slab)."""
+    a_kmajor / w_kmajor, given as [K, M] / [K, N] (K rows; need not be a multiple of the K-slab).
+    static_scratch=True: stdiff_gemm_static_scratch -- split-K partials in the library's own device array, nothing is
+    allocated by the library (`out` must be given for the CALLER not to allocate either)."""
     require_gpu(A, W, bias, out, gate, res, out2, workspace)
     bk = 64 if A.element_size() == 2 else 16
     kA = A.shape[0] if a_kmajor else A.shape[1]
@@ -50,7 +52,8 @@ def gemm(A, W, bias=None, out=None, out_dtype=None, epi=L.EPI_BIAS, gate=None, r
         a.C2, a.ldc2 = ptr(out2), out2.stride(0)
     if workspace is not None:          # fp32 scratch for split-K (small outputs with a long K)
         a.workspace, a.workspace_bytes = ptr(workspace), workspace.numel() * workspace.element_size()
-    check(lib_for(A, W, out, gate, out2).stdiff_gemm(C.byref(a), stream()))
+    lb = lib_for(A, W, out, gate, out2)
+    check((lb.stdiff_gemm_static_scratch if static_scratch else lb.stdiff_gemm)(C.byref(a), stream()))
     return out
 
 
