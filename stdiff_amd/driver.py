@@ -45,13 +45,15 @@ def fold_mask(gene_num, test_ind):
 def diffusion_impute(data_seq_array, data_spatial_array, *, lr=0.00016046744893538737, depth=6, num_epoch=900,
                      diffusion_step=1500, batch_size=512, hidden_size=1024, head=16, n_splits=5, rand=0,
                      device=torch.device('cuda:0'), save_dir=None, folds=None, compute_dtype=None, is_tqdm=False,
-                     device_loader=True, sample_seed=None):
+                     device_loader=True, sample_seed=None, sample_noise=None):
     """Returns (impu [cells, genes] in [0,1], with every gene imputed by the fold that held it out; columns of folds not
     in `folds` stay 0), like the reference's `impu`.  Defaults are the reference's (test-stDiff.py:27-34,64-70).
 
     save_dir: directory of `stDiff%d.pt` checkpoints (1-based fold index, :88); existing files are loaded instead of
     training, new ones are written after training (the reference has the save commented out; loading is what makes
-    its checkpoints usable here: same state-dict keys)."""
+    its checkpoints usable here: same state-dict keys).
+    sample_noise (parity runs): callable, 1-based fold index -> (x_T [cells, genes], step_noise [steps-1, cells, genes])
+    injected into sample_stDiff in place of the in-kernel Philox draws."""
     seq0 = np.ascontiguousarray(data_seq_array, dtype=np.float32)
     st0 = np.ascontiguousarray(data_spatial_array, dtype=np.float32)
     cell_num, gene_num = st0.shape
@@ -92,10 +94,14 @@ def diffusion_impute(data_seq_array, data_spatial_array, *, lr=0.000160467448935
         dataloader = get_data_loader(data_spatial_masked, data_spatial_masked, batch_size=batch_size, is_shuffle=False,
                                      **loader_kw)
         model.eval()
+        inject = {}
+        if sample_noise is not None:
+            inject["x_T"], inject["step_noise"] = sample_noise(idx)
         imputation = sample_stDiff(model, device=device, dataloader=dataloader, noise_scheduler=noise_scheduler,
                                    mask=mask, gt=data_spatial_masked, num_step=diffusion_step,
                                    sample_shape=(cell_num, gene_num), is_condi=True,
                                    sample_intermediate=diffusion_step, model_pred_type='noise',
-                                   is_classifier_guidance=False, omega=0.2, is_tqdm=is_tqdm, seed=sample_seed)
+                                   is_classifier_guidance=False, omega=0.2, is_tqdm=is_tqdm, seed=sample_seed,
+                                   **inject)
         all_pred_res[:, test_ind] = imputation[:, test_ind]          # :181
     return (all_pred_res + 1) / 2                                    # :184

@@ -105,21 +105,28 @@ class Workspace:
     def __init__(self, pw, chunk_lens, share=None):
         R = int(sum(chunk_lens))
         H, dev, tdt = pw.H, pw.device, pw.tdt
-        if R * 6 * H * (4 if pw.dtype == F32 else 2) >= 2 ** 31:
-            raise ValueError(f"{R} rows in one workspace: the kernels index activations with 32-bit byte offsets "
-                             f"(use row slabs: engine.plan_slabs)")
+        if R > slab_rows_max(pw):
+            raise ValueError(f"{R} rows in one workspace: the LDS-DMA GEMM addresses its operands with 32-bit byte "
+                             f"offsets (use row slabs: engine.plan_slabs)")
         self.R, self.chunk_lens = R, list(chunk_lens)
         cu = np.concatenate([[0], np.cumsum(chunk_lens)]).astype(np.int32)
         self.cu_rows = torch.from_numpy(cu).to(dev)
         if share is not None:
             assert share.R >= R
-        for name, width, f32 in self.BUFS:
-            if share is not None:
-                buf = getattr(share, name)[:R]
-            else:
-                buf = torch.empty((R, width * H), device=dev, dtype=torch.float32 if f32 else tdt)
-            setattr(self, name, buf)
-        self.eps = share.eps[:R] if share is not None else torch.empty((R, pw.G), device=dev, dtype=torch.float32)
+            for name, width, f32 in self.BUFS:
+                setattr(self, name, getattr(share, name)[:R])
+            self.eps = share.eps[:R]
+        else:
+            # ONE allocation for the whole set, carved at 2 MiB boundaries: a single large hipMalloc instead of nine
+            specs = [(name, width * H, torch.float32 if f32 else tdt) for name, width, f32 in self.BUFS]
+            specs.append(("eps", pw.G, torch.float32))
+            sizes = [ops.round_up(R * cols * torch.empty((), dtype=dt).element_size(), 2 << 20) for _, cols, dt in specs]
+            self.arena = torch.empty(sum(sizes), device=dev, dtype=torch.uint8)
+            off = 0
+            for (name, cols, dt), nbytes in zip(specs, sizes):
+                es = torch.empty((), dtype=dt).element_size()
+                setattr(self, name, self.arena[off:off + R * cols * es].view(dt).view(R, cols))
+                off += nbytes
         self._xp = None
         self._pw = pw
         s = L.DitWorkspace()
@@ -138,12 +145,17 @@ class Workspace:
         return self._xp
 
 
+def slab_rows_max(pw):
+    """Most rows one launch may cover: the widest GEMM A operand ([R, 4H], the MLP hidden layer) must stay below
+    2^32 bytes -- the LDS-DMA GEMM addresses operands through a buffer descriptor with 32-bit byte offsets (every
+    other kernel, and every epilogue, uses 64-bit row offsets)."""
+    return int(2.0e9 / (4 * pw.H) * (2 / (4 if pw.dtype == F32 else 2))) - 512
+
+
 def slab_rows_limit(pw):
-    """Most rows one launch may cover: every activation matrix ([R, 6H] the widest) stays below 2^31 bytes, so the
-    kernels' 32-bit byte offsets (LDS-DMA buffer descriptors) are exact.  STDIFF_SLAB_ROWS lowers it."""
-    limit = (2 ** 31 - 2 ** 20) // (6 * pw.H * (4 if pw.dtype == F32 else 2))
-    want = int(os.environ.get("STDIFF_SLAB_ROWS", "65536"))
-    return max(1, min(limit, want))
+    """Rows per slab of the reverse sampler (STDIFF_SLAB_ROWS overrides the default), capped by slab_rows_max."""
+    want = int(os.environ.get("STDIFF_SLAB_ROWS", "131072"))
+    return max(1, min(slab_rows_max(pw), want))
 
 
 def plan_slabs(chunk_lens, max_rows):

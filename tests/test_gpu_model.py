@@ -314,6 +314,35 @@ def test_cv_driver_flow(tmp_path):
     assert np.array_equal(host, a)
 
 
+def test_cv_driver_flow_matches_reference_golden(golden_dir, tmp_path):
+    """SURVEY 8(f).2 pinned by the reference: golden G8 is test-stDiff.py:62-187 run with the reference's own functions
+    (5 folds: KFold masks, [-1,1] mapping, reference training, reference sample_stDiff with recorded draws, scatter of
+    each fold's test genes, (x+1)/2).  The build's driver loads the recorded trained weights through the reference's
+    own resume path (stDiff%d.pt, :138,151), gets the recorded draws injected, and must return the same matrix."""
+    from stdiff_amd.driver import diffusion_impute
+    g = np.load(os.path.join(golden_dir, "g8_driver.npz"))
+    n_sc, n_st, G, H, depth, heads, B, T, num_epoch, n_splits, rand = [int(v) for v in g["cfg"]]
+    for idx in range(1, n_splits + 1):
+        sd = {k[len(f"sd{idx}/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"sd{idx}/")}
+        torch.save(sd, os.path.join(tmp_path, "stDiff%d.pt" % idx))
+    impu = diffusion_impute(g["seq"], g["st"], lr=float(g["lr"][0]), depth=depth, num_epoch=num_epoch, diffusion_step=T,
+                            batch_size=B, hidden_size=H, head=heads, n_splits=n_splits, rand=rand,
+                            device=torch.device(DEV), save_dir=str(tmp_path),
+                            sample_noise=lambda idx: (g[f"x_T{idx}"], g[f"z{idx}"]))
+    assert impu.shape == g["impu"].shape and impu.dtype == np.float32
+    err = float(np.abs(impu - g["impu"]).max())
+    print(f"G8 driver flow: max|impu - reference| = {err:.2e} (values in [0, 1])")
+    assert err < 2e-5
+    for idx in range(1, n_splits + 1):             # every fold scattered exactly its own test genes
+        te = g[f"test_ind{idx}"]
+        only = diffusion_impute(g["seq"], g["st"], depth=depth, num_epoch=num_epoch, diffusion_step=T, batch_size=B,
+                                hidden_size=H, head=heads, n_splits=n_splits, rand=rand, device=torch.device(DEV),
+                                save_dir=str(tmp_path), folds=[idx - 1],
+                                sample_noise=lambda i: (g[f"x_T{i}"], g[f"z{i}"])) if idx == 2 else None
+        if only is not None:
+            assert np.array_equal(only[:, te], impu[:, te])
+
+
 def test_gene_metrics_match_scipy():
     """device-side per-gene PCC / cosine / SPCC / RMSE(zscore) / SSIM(scale_max) / JS(scale_plus) against
     the reference's host formulas (test-stDiff.py:203-364, restated with numpy/scipy in float64)."""

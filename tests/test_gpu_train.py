@@ -273,18 +273,27 @@ def test_normal_train_stdiff_reduces_loss():
 
 
 # ---------------------------------------------------------------- data-parallel TrainEngine, 2 ranks sharing cuda:0
-def _ddp_worker(rank, world, port, golden_dir, q):
+def _ddp_worker(rank, world, port, golden_dir, q, backend="gloo"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    DEV = f"cuda:{rank}" if backend == "nccl" else "cuda:0"          # RCCL: one GPU per rank; gloo: both on cuda:0
+    torch.cuda.set_device(DEV)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(DEV))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from stdiff_amd.train_engine import TrainEngine
         g6 = np.load(os.path.join(golden_dir, "g6_train.npz"))
         g7 = np.load(os.path.join(golden_dir, "g7_ddp.npz"))
         C, G, H, depth, heads, seed, T = [int(v) for v in g6["cfg"]]
         m, _ = build(G, H, depth, heads, seed, "fp32")
+        m = m.to(DEV)
+        if rank == 1:                                    # rank 0's parameters must win (broadcast at construction)
+            with torch.no_grad():
+                m.blks[0].mlp.fc1.weight.add_(1.0)
         te = TrainEngine(m, lr=float(g6["lr"][0]), diffusion_step=T, mask=g6["mask"])
-        assert te.world == world
+        assert te.world == world and te.async_buckets == (backend == "nccl")
         x = torch.from_numpy(g6["x"])[rank * C:(rank + 1) * C].contiguous().to(DEV)
         xc = torch.from_numpy(g6["x_cond"])[rank * C:(rank + 1) * C].contiguous().to(DEV)
         loss, gn = te.step(x, xc, noise=torch.from_numpy(g6["noise"][rank]).to(DEV),
@@ -308,11 +317,19 @@ def _ddp_worker(rank, world, port, golden_dir, q):
         dist.destroy_process_group()
 
 
-def test_ddp_train_step_two_ranks_golden(golden_dir):
-    """SURVEY 8(e) training semantics on the GPU path: two processes (both on cuda:0, process group gloo -- the box has
-    one GPU; RCCL itself is only reached by the driver's multi-GPU runs) each run TrainEngine on ITS batch; the
-    bucketed all-reduce between backward segments, the 1/W scaling inside clip+AdamW and the update must reproduce
-    golden G7 (reference gradients of two batches averaged, one optimizer step) on both ranks."""
+def _ddp_backends():
+    # the RCCL branch (asynchronous stream-ordered buckets) needs one GPU per rank: it runs wherever two are visible
+    return ["gloo", "nccl"] if torch.cuda.device_count() >= 2 else ["gloo"]
+
+
+@pytest.mark.parametrize("backend", _ddp_backends())
+def test_ddp_train_step_two_ranks_golden(golden_dir, backend):
+    """SURVEY 8(e) training semantics on the GPU path: two processes each run TrainEngine on ITS batch; the bucketed
+    all-reduce between backward segments, the 1/W scaling inside clip+AdamW and the update must reproduce golden G7
+    (reference gradients of two batches averaged, one optimizer step) on both ranks -- also when rank 1 was built with
+    different weights (rank 0's are broadcast at construction, as torch DDP does).  backend "gloo": both ranks on
+    cuda:0 (a one-GPU box); backend "nccl" (= RCCL, asynchronous buckets): one GPU per rank, collected only where two
+    GPUs are visible."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -321,7 +338,7 @@ def test_ddp_train_step_two_ranks_golden(golden_dir):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, golden_dir, q)) for r in range(2)]
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, golden_dir, q, backend)) for r in range(2)]
     for p_ in procs:
         p_.start()
     res = [q.get(timeout=240) for _ in procs]

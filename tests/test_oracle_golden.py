@@ -161,3 +161,24 @@ def test_synthetic_data_contract():
     # the 5 folds partition the genes
     tot = sum((1 - O.kfold_mask(64, f)) for f in range(5))
     assert np.array_equal(tot, np.ones(64))
+
+
+def test_oracle_reproduces_driver_flow_golden(golden_dir):
+    """G8: per fold, the oracle's reverse loop on the recorded trained weights and draws gives the
+    reference's imputation; scattering each fold's test genes and mapping back to [0,1] gives its `impu`."""
+    g = np.load(os.path.join(golden_dir, "g8_driver.npz"))
+    n_sc, n_st, G, H, depth, heads, B, T, num_epoch, n_splits, rand = [int(v) for v in g["cfg"]]
+    st = g["st"]
+    acc = np.zeros_like(st)
+    tb = O.make_tables(T, schedule="cosine")
+    for idx in range(1, n_splits + 1):
+        p = {k[len(f"sd{idx}/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"sd{idx}/")}
+        te = g[f"test_ind{idx}"]
+        mask = np.ones((G,), dtype=np.float32)
+        mask[te] = 0
+        gt = ((st * mask) * 2 - 1).astype(np.float32)
+        z = g[f"z{idx}"]
+        zs = {t: torch.from_numpy(z[i]) for i, t in enumerate(range(T - 1, 0, -1))}
+        out = O.sample(p, tb, gt, mask, B, heads, depth, torch.from_numpy(g[f"x_T{idx}"]), lambda t: zs[t], T, T)
+        acc[:, te] = out.numpy()[:, te]
+    assert np.abs((acc + 1) / 2 - g["impu"]).max() < 1e-5

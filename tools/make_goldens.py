@@ -61,6 +61,11 @@ def _install_stubs():
 
 _install_stubs()
 sys.path.insert(0, REF)
+# the repository's own top-level `model/` package (the import shim over stdiff_amd) would win over the reference's
+# namespace package of the same name: bind the name `model` to the reference's directory explicitly
+_refpkg = types.ModuleType("model")
+_refpkg.__path__ = [os.path.join(REF, "model")]
+sys.modules["model"] = _refpkg
 from model.stDiff_model import DiT_stDiff  # noqa: E402
 from model.stDiff_scheduler import NoiseScheduler  # noqa: E402
 from model import stDiff_train as ref_train  # noqa: E402
@@ -412,14 +417,105 @@ def g6_g7():
     np.savez(os.path.join(OUT, "g7_ddp.npz"), **o7)
 
 
+# ---------------------------------------------------------------- G8: the 5-fold driver flow
+def g8():
+    """test-stDiff.py:62-187 (`diffusion_impute`) on a tiny problem.  The script itself cannot be imported (scanpy, CUDA
+    default tensor type at module level), so its call sequence is followed here line by line with the REFERENCE's own
+    DiT_stDiff / normal_train_stDiff / NoiseScheduler / sample_stDiff and sklearn's KFold; the DataLoader factory
+    (process/data.py:64-75, needs anndata and a CUDA generator) is the same two torch calls on a CPU generator.
+    Training runs for real (so the zero-initialised layers move), the trained state dicts are recorded -- the build's
+    driver then LOADS them as checkpoints `stDiff%d.pt`, which is the reference's own resume path (:138,151) -- and the
+    sampling draws are recorded so that the build can inject them."""
+    from sklearn.model_selection import KFold
+    from torch.utils.data import DataLoader, TensorDataset
+    print("G8 diffusion_impute flow: 5 folds, reference train + sample")
+    n_sc, n_st, G, H, depth, heads, B, T = 64, 48, 20, 64, 1, 2, 32, 12
+    lr, num_epoch, n_splits, rand = 0.00016046744893538737, 3, 5, 0
+    data_seq_array = O.synth_expression(n_sc, G, 41)
+    data_spatial_array = O.synth_expression(n_st, G, 42)
+
+    def get_data_loader(data_ary, cell_type, batch_size=512, is_shuffle=True):
+        ds = TensorDataset(torch.from_numpy(data_ary.astype(np.float32)), torch.from_numpy(cell_type.astype(np.float32)))
+        gen = torch.Generator(device="cpu")
+        return DataLoader(ds, batch_size=batch_size, shuffle=is_shuffle, drop_last=False, generator=gen)
+
+    kf = KFold(n_splits=n_splits, shuffle=True, random_state=rand)                      # :73
+    torch.manual_seed(10)                                                               # :75
+    idx = 1
+    all_pred_res = np.zeros_like(data_spatial_array)
+    out = dict(cfg=np.array([n_sc, n_st, G, H, depth, heads, B, T, num_epoch, n_splits, rand]), lr=np.array([lr]),
+               seq=data_seq_array, st=data_spatial_array)
+    real_randn, real_randn_like = torch.randn, torch.randn_like
+    for train_ind, test_ind in kf.split(np.arange(G)):                                  # :79
+        cell_num, gene_num = data_spatial_array.shape
+        mask = np.ones((gene_num,), dtype="float32")                                    # :92-96
+        mask[test_ind] = 0
+        seq, st = data_seq_array, data_spatial_array
+        data_seq_masked, data_spatial_masked = seq * mask, st * mask                    # :100-101
+        seq = seq * 2 - 1                                                               # :103-108
+        data_seq_masked = data_seq_masked * 2 - 1
+        data_spatial_masked = data_spatial_masked * 2 - 1
+        dataloader = get_data_loader(seq, data_seq_masked, batch_size=B, is_shuffle=True)
+        torch.manual_seed(1202)                                                         # :116-119
+        model = DiT_stDiff(input_size=gene_num, hidden_size=H, depth=depth, num_heads=heads, classes=6,
+                           mlp_ratio=4.0, dit_type="dit")                               # :121-129
+        model.to(CPU)
+        model.train()
+        ref_train.normal_train_stDiff(model, dataloader=dataloader, lr=lr, num_epoch=num_epoch, diffusion_step=T,
+                                      device=CPU, pred_type="noise", mask=mask, is_tqdm=False)   # :140-147
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        assert float(sd["out_layer.linear.weight"].abs().max()) > 0                     # training moved the zero layers
+        gt = data_spatial_masked                                                        # :153
+        noise_scheduler = NoiseScheduler(num_timesteps=T, beta_schedule="cosine")
+        dataloader = get_data_loader(data_spatial_masked, data_spatial_masked, batch_size=B, is_shuffle=False)
+        model.eval()
+        rng = np.random.default_rng(800 + idx)
+        x_T = torch.from_numpy(rng.standard_normal((cell_num, gene_num), dtype=np.float32))
+        z = [torch.from_numpy(rng.standard_normal((cell_num, gene_num), dtype=np.float32)) for _ in range(T - 1)]
+        zq = list(z)
+        ref_sample.torch.randn = lambda *a, **k: x_T.clone()
+        ref_sched.torch.randn_like = lambda a: zq.pop(0)
+        try:
+            imputation = ref_sample.sample_stDiff(model, device=CPU, dataloader=dataloader,
+                                                  noise_scheduler=noise_scheduler, mask=mask, gt=gt, num_step=T,
+                                                  sample_shape=(cell_num, gene_num), is_condi=True,
+                                                  sample_intermediate=T, model_pred_type="noise",
+                                                  is_classifier_guidance=False, omega=0.2)     # :167-179
+        finally:
+            torch.randn, torch.randn_like = real_randn, real_randn_like
+        assert not zq
+        all_pred_res[:, test_ind] = imputation[:, test_ind]                             # :181
+        # the oracle reproduces the reference's sampling of this fold
+        zs = {t: z[i] for i, t in enumerate(range(T - 1, 0, -1))}
+        of = O.sample({k: v for k, v in sd.items()}, O.make_tables(T, schedule="cosine"), gt.astype(np.float32), mask, B,
+                      heads, depth, x_T, lambda t: zs[t], T, T)
+        check(f"G8 fold {idx} sample (oracle vs reference)", of, torch.from_numpy(imputation), 1e-4)
+        for k, v in sd.items():
+            out[f"sd{idx}/{k}"] = v.numpy()
+        out[f"x_T{idx}"] = x_T.numpy()
+        out[f"z{idx}"] = np.stack([t.numpy() for t in z])
+        out[f"test_ind{idx}"] = test_ind
+        idx += 1
+    impu = (all_pred_res + 1) / 2                                                       # :184
+    out["impu"] = impu.astype(np.float32)
+    np.savez(os.path.join(OUT, "g8_driver.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    g3_g4()
-    g1_g2()
-    g5()
-    g6_g7()
+    only = sys.argv[1] if len(sys.argv) > 1 else None        # e.g. `python tools/make_goldens.py g8`: one group only
+    if only in (None, "g3", "g4"):
+        g3_g4()
+    if only in (None, "g1", "g2"):
+        g1_g2()
+    if only in (None, "g5"):
+        g5()
+    if only in (None, "g6", "g7"):
+        g6_g7()
+    if only in (None, "g8"):
+        g8()
     print("goldens written to", OUT)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):

@@ -7,7 +7,7 @@ count; the LAST 99 gemm dispatches of each pass are those.  Per launch:
 (FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, so it is doubled:
 MI355X_MICROARCH.md, HBM section).  Writes profiles/gemm_traffic.json {"<dtype>": bytes per launch, ...}.
 
-usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <dtype> [out.json]"""
+usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <dtype> <rows_per_launch> [out.json]"""
 import csv
 import glob
 import json
@@ -26,13 +26,15 @@ def last_gemm(dirname, counter, n=99):
 
 
 def main():
-    fdir, wdir, dtype = sys.argv[1:4]
-    out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(__file__), "..", "profiles", "gemm_traffic.json")
+    fdir, wdir, dtype, rows = sys.argv[1:5]
+    out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(os.path.dirname(__file__), "..", "profiles", "gemm_traffic.json")
     fetch, write = last_gemm(fdir, "FETCH_SIZE"), last_gemm(wdir, "WRITE_SIZE")
     f_kib = sum(v for _, v in fetch) / len(fetch)
     w_kib = sum(v for _, v in write) / len(write)
     per_launch = (2.0 * f_kib + w_kib) * 1024.0
     rec = json.load(open(out)) if os.path.isfile(out) else {}
+    if rec.get("rows_per_launch") != int(rows):
+        rec = {"rows_per_launch": int(rows)}            # figures of another slab size do not mix
     rec[dtype] = round(per_launch)
     rec[dtype + "_detail"] = {"fetch_kib_raw_avg": round(f_kib, 1), "write_kib_avg": round(w_kib, 1),
                               "launches_averaged": len(fetch), "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024"}
