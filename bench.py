@@ -50,7 +50,9 @@ def flops_per_row(chunk):
 
 
 def gemm_launches(eng, ws):
-    """(M, N, K, closure) of every dense-contraction launch of one denoiser forward over the slab `ws`, in order."""
+    """(M, N, K, closure) of every dense-contraction launch of one denoiser forward over the slab `ws`, in order --
+    the launches stdiff_dit_forward makes for this workspace (fused-LN form: the adaLN projection of a block is three
+    launches -- gates, shift/scale of LN1 with the LayerNorm in its epilogue, the same for LN2 -- with the same FLOPs)."""
     from stdiff_amd import _lib as L
     from stdiff_amd import ops
     pw = eng.pw
@@ -60,27 +62,43 @@ def gemm_launches(eng, ws):
     def add(A, W, b, o, **kw):
         out.append((R, W.shape[0], W.shape[1], lambda: ops.gemm(A, W, b, out=o, **kw)))
     add(ws.xp, pw.w["in_layer.0.weight"], pw.b("in_layer.0.bias"), ws.h)
+    if ws.fused:
+        pw.ensure_fused()
+        parts = ws.ln_parts.view(R, -1, 2)                   # [R, H/256, 2] partial row moments of h
+        ln = dict(epi=L.EPI_LN_MOD, res=ws.h, ln_parts=parts)
+        st = dict(stats_out=parts)
+        gate1, gate2 = ws.gates[:, :H], ws.gates[:, H:]
+    else:
+        st = {}
+        gate1, gate2 = ws.mod[:, 2 * H:3 * H], ws.mod[:, 5 * H:6 * H]
     for k in range(pw.depth):
         p = f"blks.{k}."
-        add(ws.s, pw.w[p + "adaLN_modulation.1.weight"], pw.b(p + "adaLN_modulation.1.bias"), ws.mod)
+        if ws.fused:
+            add(ws.s, pw.fused[f"{k}.gate_w"], pw.fused[f"{k}.gate_b"], ws.gates)
+            add(ws.s, pw.fused[f"{k}.ln1_w"], pw.fused[f"{k}.ln1_b"], ws.xn, **ln)
+        else:
+            add(ws.s, pw.w[p + "adaLN_modulation.1.weight"], pw.b(p + "adaLN_modulation.1.bias"), ws.mod)
         add(ws.xn, pw.w[p + "attn.qkv.weight"], pw.b(p + "attn.qkv.bias"), ws.qkv)
-        add(ws.o, pw.w[p + "attn.proj.weight"], pw.b(p + "attn.proj.bias"), ws.h, epi=L.EPI_GATE_RES,
-            gate=ws.mod[:, 2 * H:3 * H], res=ws.h)
+        add(ws.o, pw.w[p + "attn.proj.weight"], pw.b(p + "attn.proj.bias"), ws.h, epi=L.EPI_GATE_RES, gate=gate1, res=ws.h, **st)
+        if ws.fused:
+            add(ws.s, pw.fused[f"{k}.ln2_w"], pw.fused[f"{k}.ln2_b"], ws.xn, **ln)
         add(ws.xn, pw.w[p + "mlp.fc1.weight"], pw.b(p + "mlp.fc1.bias"), ws.u, epi=L.EPI_GELU)
-        add(ws.u, pw.w[p + "mlp.fc2.weight"], pw.b(p + "mlp.fc2.bias"), ws.h, epi=L.EPI_GATE_RES,
-            gate=ws.mod[:, 5 * H:6 * H], res=ws.h)
-    add(ws.s, pw.w["out_layer.adaLN_modulation.1.weight"], pw.b("out_layer.adaLN_modulation.1.bias"), ws.fmod)
+        add(ws.u, pw.w[p + "mlp.fc2.weight"], pw.b(p + "mlp.fc2.bias"), ws.h, epi=L.EPI_GATE_RES, gate=gate2, res=ws.h, **st)
+    if ws.fused:
+        add(ws.s, pw.fused["f.ln_w"], pw.fused["f.ln_b"], ws.xn, **ln)
+    else:
+        add(ws.s, pw.w["out_layer.adaLN_modulation.1.weight"], pw.b("out_layer.adaLN_modulation.1.bias"), ws.fmod)
     add(ws.xn, pw.w["out_layer.linear.weight"], pw.b("out_layer.linear.bias"), ws.eps)
     return out
 
 
 def measure_gemm_roofline(eng, ws, dtype, reps=3):
-    """Average launch duration of the dominant kernel (the GEMM) with HIP events on the launch stream, over the 33
-    launches of one denoiser forward of a full row slab (the unit the timed loop launches); achieved = algorithmic
-    FLOPs (2MNK) / time."""
+    """Average launch duration of the dominant kernel (the GEMM) with HIP events on the launch stream, over the GEMM
+    launches of one denoiser forward of a full row slab (the unit the timed loop launches: 45 in the fused-LN form,
+    33 in the plain one, the same 2MNK in total); achieved = algorithmic FLOPs (2MNK) / time."""
     launches = gemm_launches(eng, ws)
     flops = sum(2.0 * m * n * k for m, n, k, _ in launches)
-    for buf in (ws.xp, ws.s, ws.xn, ws.o, ws.u, ws.h, ws.mod):
+    for buf in (ws.xp, ws.s, ws.xn, ws.o, ws.u, ws.h, ws.gates if ws.fused else ws.mod):
         buf.normal_(0, 0.5)
     for _, _, _, f in launches:
         f()
@@ -107,7 +125,7 @@ def measure_gemm_roofline(eng, ws, dtype, reps=3):
     return {"bound": "mfma", "kernel": "gemm256q_kernel" if dtype != "fp32" else "gemm_nt_kernel<float>",
             "achieved": round(achieved, 1), "peak": PEAK[dtype], "unit": "TFLOP/s",
             "frac": round(achieved / PEAK[dtype], 4), "traffic": traffic,
-            "rows_per_launch": ws.R, "launches_per_slab": len(launches), "avg_launch_us": round(avg_ms * 1e3, 1),
+            "rows_per_launch": ws.R, "fused_ln": bool(ws.fused), "launches_per_slab": len(launches), "avg_launch_us": round(avg_ms * 1e3, 1),
             "flops_per_launch": flops / len(launches)}
 
 
@@ -127,9 +145,13 @@ def measure_hbm_kernels(eng, ws, sched, gt, mask, dtype, reps=10):
     x = torch.randn(R, G, device=dev)
     ws.h.normal_()
     ws.eps.normal_()
+    mod = (ws.mod if not ws.fused else torch.randn(R, 2 * H, device=dev).to(ws.xn.dtype))
+    parts1 = torch.empty((R, 1, 2), device=dev)
     cases = {
-        "ln_modulate_kernel": (lambda: ops.ln_modulate(ws.h, ws.mod[:, 0:H], ws.mod[:, H:2 * H], out=ws.xn),
+        "ln_modulate_kernel": (lambda: ops.ln_modulate(ws.h, mod[:, 0:H], mod[:, H:2 * H], out=ws.xn),
                                R * H * (4 + 3 * s_el)),
+        "ln_modulate_kernel (statistics only: the LayerNorm pass of the fused-LN form)":
+            (lambda: ops.row_stats(ws.h, parts1), R * H * 4),
         "silu_cond_kernel": (lambda: ops.silu_cond(ycond, temb=temb, t_index=t_dev, out=ws.s), R * H * (4 + s_el)),
         "ddpm_step_kernel": (lambda: ops.ddpm_step(x, ws.eps, gt[:R], mask, coef, t_dev, T // 2, seed=1, xp=ws.xp),
                              R * G * (16 + s_el)),

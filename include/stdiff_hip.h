@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define STDIFF_ABI_VERSION 6
+#define STDIFF_ABI_VERSION 7
 
 enum { STDIFF_F32 = 0, STDIFF_BF16 = 1 };
 
@@ -48,7 +48,15 @@ enum {
     STDIFF_EPI_GATE_RES = 3,  /* C = res[m,n] + gate[m,n] * v  (fp32 C)  (gated residual, stDiff_model.py:114,116) */
     STDIFF_EPI_ADD = 4,       /* C = v + res[m,n]                        (c = t + y, stDiff_model.py:237) */
     STDIFF_EPI_GELU_SAVE = 5, /* C = gelu_erf(v), C2 = v (C2 required)   (training: keep the pre-activation) */
-    STDIFF_EPI_ACCUM = 6      /* C = C + v  (fp32 C)                      (gradient accumulation) */
+    STDIFF_EPI_ACCUM = 6,     /* C = C + v  (fp32 C)                      (gradient accumulation) */
+    /* adaLN projection fused with the LayerNorm + modulate it feeds (stDiff_model.py:105-108 with :41-44,96,99,126):
+     * the N = 2*Hn weight rows come in 256-row tiles [128 shift rows | the 128 scale rows of the same features], and
+     *   C[m, 128*j + c] = LN(x[m,:])[128*j + c] * (1 + scale) + shift,   j = tile, c < 128,   C: [M, N/2] 16-bit,
+     * with x = `res` (fp32, the residual stream), LN from the per-row statistics `ln_parts` (below) and shift / scale
+     * rounded to the 16-bit format first: what stdiff_gemm(EPI_BIAS) into a 16-bit buffer followed by
+     * stdiff_ln_modulate gives (bit for bit when the statistics come from stdiff_row_stats), without writing shift /
+     * scale or re-reading them.  16-bit operands, N % 256 == 0, 16-byte aligned rows. */
+    STDIFF_EPI_LN_MOD = 7
 };
 
 int stdiff_abi_version(void);
@@ -83,6 +91,15 @@ typedef struct {
      * operands count as zero, so a batch that is not a multiple of the K-slab needs no padded copy either; row-major
      * operands must then really have K columns. */
     int a_layout, w_layout, k_valid;
+    /* Row statistics of a residual stream [M, Hn] as partial moments, fp32 [M][parts][2] = (mean_p, M2_p) of `parts`
+     * equal column ranges (M2 = sum of squared deviations from mean_p); mean = avg(mean_p), biased variance =
+     * (sum M2_p + cols_per_part * sum (mean_p - mean)^2) / Hn.
+     *   ln_parts / ln_nparts: read by STDIFF_EPI_LN_MOD for its `res` (Hn = N/2).
+     *   stats_out: if non-NULL (fp32 C, N % 256 == 0, 16-bit operands) this GEMM also WRITES the partial moments of the
+     *   rows of C it produces, one part per 256-column tile ([M][N/256][2]): the epilogue that adds the gated branch
+     *   to the residual stream hands the next LayerNorm its statistics, and no pass over C is needed for them. */
+    const float* ln_parts; int ln_nparts;
+    float* stats_out;
 } stdiff_gemm_args;
 int stdiff_gemm(const stdiff_gemm_args* a, void* stream);
 
@@ -125,6 +142,11 @@ int stdiff_attention_bwd(const void* qkv, int ldqkv, const void* out, int ldo, c
  * Optionally writes mean/rstd (fp32 [R]) for backward. */
 int stdiff_ln_modulate(const float* x, int ldx, const void* shift, const void* scale, int ldmod, int mod_dtype,
                        void* y, int ldy, int out_dtype, float* mean, float* rstd, int R, int H, void* stream);
+
+/* The statistics pass of the above alone, in the partial-moment form of stdiff_gemm_args with ONE part:
+ * parts[r] = (mean, sum (x - mean)^2) of x[r, :H] (same reduction order as stdiff_ln_modulate, so rsqrt(M2/H + 1e-6) is
+ * its rstd bit for bit); feeds the STDIFF_EPI_LN_MOD epilogue of stdiff_gemm. */
+int stdiff_row_stats(const float* x, int ldx, float* parts, int R, int H, void* stream);
 
 /* s[r,:] = silu(c[r,:])  with  c[r,:] = temb[*t_index, :] + ycond[r,:]  when temb != NULL (sampling: every row of a
  * reverse step shares t, model/sample.py:11), else c = ycond (training: c precomputed).   (nn.SiLU of
@@ -259,13 +281,24 @@ int stdiff_rank_corr(const float* xt, const float* yt, long long ldt, double* pa
 /* ---------------------------------------------------------------- whole-denoiser forward (inference)
  * DiT_stDiff.forward after the conditioning (stDiff_model.py:240-243): in_layer, depth x DiTblock, FinalLayer,
  * on R rows split into chunks (attention is per chunk).  Inputs: xp = packed x [R,Gp], s = silu(c) [R,H].
- * All buffers are caller-owned (torch).  Enqueues ~8 kernels per block on `stream`. */
+ * All buffers are caller-owned (torch).  Enqueues ~8 kernels per block on `stream`.
+ * Two equivalent forms (bit-identical results): the plain one (adaLN GEMM -> [R,6H]; LayerNorm+modulate kernels), and the
+ * fused-LN one for 16-bit operands, where each LayerNorm+modulate is the EPILOGUE of the adaLN GEMM that produces its
+ * shift / scale (STDIFF_EPI_LN_MOD): the [R,6H] modulation matrix is never written, and the LayerNorm's statistics come
+ * from the epilogue that wrote the residual stream (stats_out; H % 256 == 0) or from stdiff_row_stats.  The two forms
+ * agree to rounding (bit for bit when H % 256 != 0); a given build / shape always takes the same one. */
 typedef struct {
     const void* qkv_w; const float* qkv_b;
     const void* proj_w; const float* proj_b;
     const void* fc1_w; const float* fc1_b;
     const void* fc2_w; const float* fc2_b;
     const void* ada_w; const float* ada_b;
+    /* fused-LN form of the adaLN projection (optional: NULL = not packed).  ln1 / ln2: [2H, H] rows in 256-row tiles
+     * [128 shift | 128 scale] of (shift_msa, scale_msa) resp. (shift_mlp, scale_mlp), biases permuted alike;
+     * gate: [2H, H] = [gate_msa ; gate_mlp] rows. */
+    const void* ln1_w; const float* ln1_b;
+    const void* ln2_w; const float* ln2_b;
+    const void* gate_w; const float* gate_b;
 } stdiff_block_weights;
 typedef struct {
     int dtype, G, Gp, H, heads, depth;
@@ -273,12 +306,16 @@ typedef struct {
     const void* out_w; const float* out_b;     /* [G,H]  */
     const void* fada_w; const float* fada_b;   /* [2H,H] */
     const stdiff_block_weights* blocks;        /* host array [depth] */
+    const void* lnf_w; const float* lnf_b;     /* final adaLN in the fused-LN tile order (optional) */
 } stdiff_dit_weights;
 typedef struct {
     int R, n_chunks, max_chunk_rows;
     const int32_t* cu_rows;                    /* device int32 [n_chunks+1] */
     float* h;                                  /* [R,H]  residual stream */
     void* mod; void* xn; void* qkv; void* o; void* u; void* fmod;   /* [R,6H] [R,H] [R,3H] [R,H] [R,4H] [R,2H] */
+    /* fused-LN path (taken when both are non-NULL and the weights carry their fused form; mod / fmod may then be
+     * NULL): partial row moments fp32 [R][max(1, H/256)][2] and the two gates of a block [R, 2H] */
+    float* ln_parts; void* gates;
 } stdiff_dit_workspace;
 int stdiff_dit_forward(const stdiff_dit_weights* w, const stdiff_dit_workspace* ws, const void* xp, const void* s,
                        float* eps, int ldeps, void* stream);

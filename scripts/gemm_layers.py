@@ -11,14 +11,14 @@ eng = model.engine()
 lens = [min(512, R - i) for i in range(0, R, 512)]
 ws = eng.workspace(lens)
 L = B.gemm_launches(eng, ws)
-for buf in (ws.xp, ws.s, ws.xn, ws.o, ws.u, ws.h, ws.mod):
+for buf in (ws.xp, ws.s, ws.xn, ws.o, ws.u, ws.h, ws.gates if ws.fused else ws.mod):
     buf.normal_(0, 0.5)
 import time
 t0 = time.time()
 while time.time() - t0 < 2.0:          # a fresh box ramps its clocks for a second or two
     for _, _, _, f in L: f()
     torch.cuda.synchronize()
-names = ["in"] + ["ada", "qkv", "proj", "fc1", "fc2"] * 6 + ["fada", "out"]
+names = ["in"] + (["gate", "ln1", "qkv", "proj", "ln2", "fc1", "fc2"] if ws.fused else ["ada", "qkv", "proj", "fc1", "fc2"]) * 6 + ["fada", "out"]
 tot = {}
 for rep in range(5):
     evs = []
@@ -31,7 +31,7 @@ for rep in range(5):
 s = fl_all = 0
 for nm, (ms, cnt, fl) in tot.items():
     us = ms / cnt * 1e3
-    k = 6 if nm in ("ada", "qkv", "proj", "fc1", "fc2") else 1
+    k = 6 if nm in ("ada", "qkv", "proj", "fc1", "fc2", "gate", "ln1", "ln2") else 1
     s += us * k; fl_all += fl * k
     print(f"{nm:5s} {us:8.1f} us  {fl/us/1e6:7.0f} TF   per forward {us * k:8.1f} us")
 print(f"sum per forward {s:.1f} us = {fl_all / s / 1e6:.0f} TF  (R={R}, {dtype}, env TILE={os.environ.get('STDIFF_GEMM_TILE')})")

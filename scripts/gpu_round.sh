@@ -10,7 +10,7 @@ ok_rc() { [ "$1" -eq 0 ] || [ "$1" -eq 1 ]; }     # 1 = ordinary test / assertio
 for step in "$@"; do
   case $step in
     tests)
-      timeout -k 10 840 python -u -m pytest tests -m gpu -x -q --timeout 400 --timeout-method thread -p no:cacheprovider > $out/pytest.log 2>&1
+      timeout -k 10 1020 python -u -m pytest tests -m gpu -x -q --timeout 400 --timeout-method thread -p no:cacheprovider > $out/pytest.log 2>&1
       rc=$?; tail -15 $out/pytest.log; echo "tests rc=$rc"; ok_rc $rc || exit $rc ;;
     bench)
       timeout -k 10 420 python -u bench.py > $out/bench.json 2> $out/bench.err

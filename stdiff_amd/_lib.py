@@ -9,7 +9,7 @@ import os
 import torch
 
 F32, BF16, F16 = 0, 1, 2         # F16 exists on the Python side only: it selects the fp16 build, whose C code is 1
-EPI_BIAS, EPI_SILU, EPI_GELU, EPI_GATE_RES, EPI_ADD, EPI_GELU_SAVE, EPI_ACCUM = range(7)
+EPI_BIAS, EPI_SILU, EPI_GELU, EPI_GATE_RES, EPI_ADD, EPI_GELU_SAVE, EPI_ACCUM, EPI_LN_MOD = range(8)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstdiff_hip.so")
@@ -29,7 +29,8 @@ class GemmArgs(C.Structure):
                 ("res", vp), ("ldres", i32),
                 ("C2", vp), ("ldc2", i32),
                 ("workspace", vp), ("workspace_bytes", C.c_longlong),
-                ("a_layout", i32), ("w_layout", i32), ("k_valid", i32)]
+                ("a_layout", i32), ("w_layout", i32), ("k_valid", i32),
+                ("ln_parts", vp), ("ln_nparts", i32), ("stats_out", vp)]
 
 
 class StepArgs(C.Structure):
@@ -42,18 +43,19 @@ class StepArgs(C.Structure):
 
 class BlockWeights(C.Structure):
     _fields_ = [(n, vp) for n in ("qkv_w", "qkv_b", "proj_w", "proj_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b",
-                                  "ada_w", "ada_b")]
+                                  "ada_w", "ada_b", "ln1_w", "ln1_b", "ln2_w", "ln2_b", "gate_w", "gate_b")]
 
 
 class DitWeights(C.Structure):
     _fields_ = [("dtype", i32), ("G", i32), ("Gp", i32), ("H", i32), ("heads", i32), ("depth", i32),
                 ("in_w", vp), ("in_b", vp), ("out_w", vp), ("out_b", vp), ("fada_w", vp), ("fada_b", vp),
-                ("blocks", C.POINTER(BlockWeights))]
+                ("blocks", C.POINTER(BlockWeights)), ("lnf_w", vp), ("lnf_b", vp)]
 
 
 class DitWorkspace(C.Structure):
     _fields_ = [("R", i32), ("n_chunks", i32), ("max_chunk_rows", i32), ("cu_rows", vp),
-                ("h", vp), ("mod", vp), ("xn", vp), ("qkv", vp), ("o", vp), ("u", vp), ("fmod", vp)]
+                ("h", vp), ("mod", vp), ("xn", vp), ("qkv", vp), ("o", vp), ("u", vp), ("fmod", vp),
+                ("ln_parts", vp), ("gates", vp)]
 
 
 class AdamWArgs(C.Structure):
@@ -72,6 +74,7 @@ _SIGS = {
     "stdiff_transpose": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "stdiff_attention_fwd": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "stdiff_ln_modulate": (i32, [vp, i32, vp, vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, vp]),
+    "stdiff_row_stats": (i32, [vp, i32, vp, i32, i32, vp]),
     "stdiff_silu_cond": (i32, [vp, vp, vp, i32, vp, i32, i32, i32, i32, vp]),
     "stdiff_timestep_embedding": (i32, [vp, vp, vp, i32, i32, i32, vp]),
     "stdiff_pack_rows": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
@@ -123,7 +126,7 @@ def lib(fp16=False):
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.stdiff_abi_version() != 6:
+        if L.stdiff_abi_version() != 7:
             raise RuntimeError(f"{base} ABI version mismatch")
         if L.stdiff_h16_format() != int(bool(fp16)):
             raise RuntimeError(f"{base} was built with the wrong 16-bit operand format")

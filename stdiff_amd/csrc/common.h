@@ -126,6 +126,14 @@ __device__ __forceinline__ f32x4 gelu_poly4(f32x4 x) {
     return x * (xc * q + 0.5f);
 }
 
+// LayerNorm + modulate of one element, written once so that every kernel that applies it (ln_modulate_kernel and the
+// LN-modulate epilogue of the adaLN GEMM) rounds identically:  ((v - mean) * rstd) * (1 + scale) + shift, the last
+// multiply-add as ONE fused operation.
+__device__ __forceinline__ float ln_mod_apply(float v, float mean, float rstd, float scale, float shift) {
+    const float t = (v - mean) * rstd;
+    return __builtin_fmaf(t, 1.0f + scale, shift);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -63,6 +63,8 @@ struct Params {
     // gemm256q work units: units [0, t_full) are whole 256 x 256 tiles; unit t_full + 2j + h is the 128-row half h of
     // tile t_full + j (the tiles of a short last round are cut in two so that the round costs about half)
     int t_full, units;
+    const float* ln_parts; int ln_nparts;         // STDIFF_EPI_LN_MOD: partial row moments of `res` [M][parts][2]
+    float* stats_out;                             // gate-residual epilogue: partial row moments of C [M][tiles_n][2]
 };
 
 __device__ __forceinline__ void tile_of(int bid, int nblk, int tiles_m, int tiles_n, int& tm, int& tn) {
@@ -493,7 +495,7 @@ __device__ __forceinline__ f32x4 lds_read16(unsigned addr) {
 // row) of batch b + 1 are requested BEFORE batch b is read from the image, converted and stored: their HBM latency
 // (8 batches per tile, ~1.5 us each when exposed) runs under the previous batch and under the put + barrier of the
 // next quarter.  Fully unrolled so that the two register sets are static.
-template <bool CBF>
+template <bool CBF, bool STATS = false>
 __device__ __forceinline__ void epi_tile256_gate_res(const Params& p, const f32x4 (&acc)[2][2][4][2], unsigned cla,
                                                      int wid, int lane, int m0, int n0, int nq) {
     asm volatile("" : "+v"(lane));       // per-lane offsets are recomputed per tile, not kept live across the K loop
@@ -555,6 +557,23 @@ __device__ __forceinline__ void epi_tile256_gate_res(const Params& p, const f32x
                 g[3] = bf_hi(graw[slot][ps][1]);
                 v[ps] = r[slot][ps] + g * (v[ps] + bias4);
                 asm volatile("" : "+v"(v[ps]));          // keep the math out of the predicated blocks
+            }
+            if constexpr (STATS) {
+                // the 64 lanes of this wave hold one whole 256-column row of the new residual stream per `ps`: its
+                // partial moments (mean_p, M2_p) go to the next LayerNorm (stdiff_gemm_args.stats_out)
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const float mp = wave_sum((v[ps][0] + v[ps][1]) + (v[ps][2] + v[ps][3])) * (1.0f / 256.0f);
+                    float q2 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float d = v[ps][j] - mp; q2 += d * d; }
+                    q2 = wave_sum(q2);
+                    const int gm = row_of(b, ps);
+                    if (lane == 0 && gm < p.M) {
+                        float* o = p.stats_out + ((size_t)gm * p.tiles_n + (n0 >> 8)) * 2;
+                        o[0] = mp; o[1] = q2;
+                    }
+                }
             }
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
@@ -622,6 +641,129 @@ __device__ __forceinline__ void epi_tile256_bf16(const Params& p, const f32x4 (&
             if (gm < p.M && gn < p.N) __builtin_nontemporal_store(v, (u32x4*)((bf16_t*)p.C + (size_t)gm * p.ldc + gn));
         }
         STDIFF_LGKMCNT0();
+    }
+}
+
+// Whole-tile epilogue of the two-phase kernel for the adaLN projection fused with the LayerNorm + modulate it feeds
+// (STDIFF_EPI_LN_MOD).  The tile's 256 weight rows are [128 shift | 128 scale] of the same 128 features, i.e. the B0 / B1
+// column halves: acc[mh][0] holds shift and acc[mh][1] scale for the same (row, feature) in the same lane.  The lane
+// rounds both to the 16-bit format (what the unfused path stores and re-reads), loads its 4 features of the fp32
+// residual row and the row's statistics, applies ln_mod_apply and stages the 16-bit result -- one 128-row x 128-column
+// image (32 KiB) per M half -- for 16-byte stores, 16 lanes to a 256-byte row.
+// Image: row r (256 B) holds 32 8-byte chunks; chunk c of row r sits at c ^ ((r & 15) << 1): the 16 lanes of a
+// ds_write_b64 group (16 rows, one chunk) hit 16 distinct bank pairs, and bit 0 is never flipped, so a 16-byte read
+// unit stays adjacent.
+// HBM latency is what this epilogue costs (128 KiB of residual rows per tile, one workgroup per CU), so every request
+// is in flight as early as it can be: the residual loads of the first M half (8 x 16 B per lane) go out first, thread
+// r < 256 combines row r's partial moments ONCE per tile into (mean, rstd) in LDS (2 KiB behind the image) while they
+// fly, and the second half's residual loads are issued before the first half is converted.  LDS accesses are asm for
+// the same reason as in epi_tile256_gate_res.
+__device__ __forceinline__ void lds_write8(unsigned addr, u32x2 v) {
+    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ u32x2 lds_read8(unsigned addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void epi_tile256_lnmod(const Params& p, const f32x4 (&acc)[2][2][4][2], unsigned imga,
+                                                  int tid, int wid, int lane, int m0, int n0, int nq) {
+    asm volatile("" : "+v"(lane), "+v"(tid));   // per-lane offsets are recomputed per tile, not kept live across the K loop
+    const int wr = wid >> 2, wc = wid & 3, fr = lane & 15, fq = lane >> 4;
+    const int c0 = n0 >> 1;                      // first output column of this tile
+    const unsigned sta = imga + 32768u;          // (mean, rstd) of the tile's 256 rows
+    f32x4 x[2][4][2];
+    auto issue = [&](int mh, int slot) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int gm = min(m0 + mh * 128 + wr * 64 + mt * 16 + fr, p.M - 1);
+            const float* xr = p.res + (size_t)gm * p.ldres + c0 + wc * 32 + fq * 4;
+            x[slot][mt][0] = *(const f32x4*)xr;
+            x[slot][mt][1] = *(const f32x4*)(xr + 16);
+        }
+    };
+    issue(0, 0);
+    if (tid < 256) {
+        // row statistics from the partial moments (fixed order; one part: exactly stdiff_ln_modulate's)
+        const int np = p.ln_nparts;
+        const float* pp = p.ln_parts + (size_t)min(m0 + tid, p.M - 1) * np * 2;
+        float pm[8], pq[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (q < np) {
+                const f32x2_cv t = *(const f32x2_cv*)(pp + 2 * q);
+                pm[q] = t[0];
+                pq[q] = t[1];
+            } else pm[q] = pq[q] = 0.f;
+        float mean = pm[0], m2 = pq[0];
+        if (np > 1) {
+#pragma unroll
+            for (int q = 1; q < 8; ++q)
+                if (q < np) { mean += pm[q]; m2 += pq[q]; }
+            mean /= (float)np;
+            float dev = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < np) { const float d = pm[q] - mean; dev += d * d; }
+            m2 += dev * (float)((p.N >> 1) / np);
+        }
+        const float rstd = rsqrtf(m2 / (float)(p.N >> 1) + 1e-6f);
+        u32x2 st;
+        st[0] = __float_as_uint(mean);
+        st[1] = __float_as_uint(rstd);
+        lds_write8(sta + (unsigned)tid * 8u, st);
+    }
+    f32x4 bsh[2], bsc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int gn = n0 + wc * 32 + nt * 16 + fq * 4;
+        bsh[nt] = p.bias ? *(const f32x4*)(p.bias + gn) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bsc[nt] = p.bias ? *(const f32x4*)(p.bias + gn + 128) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    STDIFF_LGKMCNT0();
+    STDIFF_BARRIER();
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+        if (2 * mh >= nq) break;                         // half unit: rows of acc[0] only
+        if (mh) STDIFF_BARRIER();                        // image reads of the first half are done
+        if (mh == 0 && nq > 2) issue(1, 1);
+        u32x2 st[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) st[mt] = lds_read8(sta + (unsigned)(mh * 128 + wr * 64 + mt * 16 + fr) * 8u);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(st[0]), "+v"(st[1]), "+v"(st[2]), "+v"(st[3])::"memory");
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int r = wr * 64 + mt * 16 + fr;
+            const float mean = __uint_as_float(st[mt][0]), rstd = __uint_as_float(st[mt][1]);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const f32x4 sh = acc[mh][0][mt][nt] + bsh[nt], sc = acc[mh][1][mt][nt] + bsc[nt];
+                const f32x4 xv = x[mh][mt][nt];
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = ln_mod_apply(xv[j], mean, rstd, bf2f(f2bf(sc[j])), bf2f(f2bf(sh[j])));
+                u32x2 rr;
+                rr[0] = pack2bf(o[0], o[1]);
+                rr[1] = pack2bf(o[2], o[3]);
+                const int c = wc * 8 + nt * 4 + fq;
+                lds_write8(imga + (unsigned)(r * 256 + ((c ^ ((r & 15) << 1)) << 3)), rr);
+            }
+        }
+        STDIFF_LGKMCNT0();
+        STDIFF_BARRIER();
+        const int pair = tid & 15, gn = c0 + pair * 8;
+        f32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = (tid >> 4) + 32 * k;
+            v[k] = lds_read16(imga + (unsigned)(row * 256 + (((2 * pair) ^ ((row & 15) << 1)) << 3)));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int gm = m0 + mh * 128 + (tid >> 4) + 32 * k;
+            if (gm < p.M) __builtin_nontemporal_store(v[k], (f32x4*)((bf16_t*)p.C + (size_t)gm * p.ldc + gn));
+        }
     }
 }
 
@@ -828,7 +970,12 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(Params p) {
     }
 }
 
-// ---- variant: two 32-MFMA phases per K-slab (see the loop comment); everything else as gemm256p_kernel
+// ---- variant: two 32-MFMA phases per K-slab (see the loop comment); everything else as gemm256p_kernel.
+// MODE selects the epilogue code that is compiled in (the kernel sits at 256 VGPRs / 104 SGPRs: every epilogue that is
+// merely present costs registers in all of them): 0 = bias / SiLU / GELU / gate*v+res / the generic quarter path,
+// 1 = the LayerNorm-modulate epilogue of the adaLN projection only, 2 = gate*v+res that also writes the partial row
+// moments of its output.
+template <int MODE>
 __global__ __launch_bounds__(512, 1) void gemm256q_kernel(Params p) {
     constexpr int ROWB = 128, HALF = 128 * ROWB;          // one half-tile = 128 rows x 64 bf16 = 16 KiB
     __shared__ __attribute__((aligned(16))) unsigned char smem[9 * HALF];
@@ -991,7 +1138,11 @@ __global__ __launch_bounds__(512, 1) void gemm256q_kernel(Params p) {
             set_tile(next, m0, n0);
             prologue();
         }
-        if (p.vec == 2 && p.c_bf16 && !p.C2 && p.epi <= STDIFF_EPI_GELU) {     // bias / SiLU / GELU, 16-byte C rows
+        if constexpr (MODE == 1) {
+            epi_tile256_lnmod(p, acc, cla, tid, wid, lane, em0, en0, nq);
+        } else if constexpr (MODE == 2) {
+            epi_tile256_gate_res<false, true>(p, acc, cla, wid, lane, em0, en0, nq);
+        } else if (p.vec == 2 && p.c_bf16 && !p.C2 && p.epi <= STDIFF_EPI_GELU) {     // bias / SiLU / GELU, 16-byte C rows
             unsigned char* img = smem + 5 * HALF;
             if (p.epi == STDIFF_EPI_GELU) epi_tile256_bf16<STDIFF_EPI_GELU>(p, acc, img, tid, wid, lane, em0, en0, nq);
             else if (p.epi == STDIFF_EPI_SILU) epi_tile256_bf16<STDIFF_EPI_SILU>(p, acc, img, tid, wid, lane, em0, en0, nq);
@@ -1119,7 +1270,7 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
     STDIFF_CHECK_ARG(a->A && a->W && a->C);
     STDIFF_CHECK_ARG(a->a_dtype == STDIFF_F32 || a->a_dtype == STDIFF_BF16);
     STDIFF_CHECK_ARG(a->c_dtype == STDIFF_F32 || a->c_dtype == STDIFF_BF16);
-    STDIFF_CHECK_ARG(a->epi >= STDIFF_EPI_BIAS && a->epi <= STDIFF_EPI_ACCUM);
+    STDIFF_CHECK_ARG(a->epi >= STDIFF_EPI_BIAS && a->epi <= STDIFF_EPI_LN_MOD);
     if (a->M == 0 || a->N == 0) return STDIFF_OK;
     const bool bf = a->a_dtype == STDIFF_BF16;
     const int bk = bf ? 64 : 16, epv = bf ? 8 : 4;
@@ -1131,12 +1282,21 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
     STDIFF_CHECK_ARG(k_valid <= a->K && (k_valid == a->K || ak || wk));
     // K-major operands: [k_valid][M] resp. [k_valid][N], 16-byte column pieces (M resp. N a multiple of 8 / 4)
     if ((ak && a->M % epv) || (wk && a->N % epv)) return STDIFF_ERR_SHAPE;
-    if ((ak ? a->lda < a->M : a->lda < a->K) || (wk ? a->ldw < a->N : a->ldw < a->K) || a->ldc < a->N) return STDIFF_ERR_ARG;
+    if ((ak ? a->lda < a->M : a->lda < a->K) || (wk ? a->ldw < a->N : a->ldw < a->K) ||
+        a->ldc < (a->epi == STDIFF_EPI_LN_MOD ? a->N / 2 : a->N))
+        return STDIFF_ERR_ARG;
     if (a->epi == STDIFF_EPI_GATE_RES) STDIFF_CHECK_ARG(a->gate && a->res && a->c_dtype == STDIFF_F32);
     if (a->epi == STDIFF_EPI_ADD) STDIFF_CHECK_ARG(a->res != nullptr);
     if (a->epi == STDIFF_EPI_ACCUM) STDIFF_CHECK_ARG(a->c_dtype == STDIFF_F32);
     if (a->epi == STDIFF_EPI_GELU_SAVE) STDIFF_CHECK_ARG(a->C2 != nullptr);
     if (a->C2) STDIFF_CHECK_ARG(a->ldc2 >= a->N);
+    const bool lnmod = a->epi == STDIFF_EPI_LN_MOD;
+    if (lnmod) {       // C is [M, N/2]; persistent 256 x 256 kernel only (its B0 / B1 halves are the shift / scale rows)
+        STDIFF_CHECK_ARG(a->res && a->ln_parts && a->ln_nparts >= 1 && a->ln_nparts <= 8 && (a->N / 2) % a->ln_nparts == 0 && !a->C2 && !ak && !wk);
+        STDIFF_CHECK_ARG(a->a_dtype == STDIFF_BF16 && a->c_dtype == STDIFF_BF16 && a->ldc >= a->N / 2 && a->ldres >= a->N / 2);
+        if (a->N % 256) return STDIFF_ERR_SHAPE;
+        if (a->ldc % 8 || a->ldres % 4 || !al16(a->C) || !al16(a->res) || (a->bias && !al16(a->bias))) return STDIFF_ERR_ALIGN;
+    }
 
     Params p;
     p.M = a->M; p.N = a->N; p.K = a->K;
@@ -1144,6 +1304,7 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
     p.C = a->C; p.ldc = a->ldc; p.c_bf16 = a->c_dtype == STDIFF_BF16;
     p.epi = a->epi; p.gate = a->gate; p.ldgate = a->ldgate; p.res = a->res; p.ldres = a->ldres;
     p.C2 = a->C2; p.ldc2 = a->ldc2;
+    p.ln_parts = a->ln_parts; p.ln_nparts = a->ln_nparts; p.stats_out = a->stats_out;
     // 4-wide pieces: fp32 needs 16-byte, bf16 8-byte alignment of every row piece
     bool vec = a->N % 8 == 0 && a->ldc % 4 == 0 && (p.c_bf16 ? al8(a->C) : al16(a->C)) && (!a->bias || al16(a->bias));
     if (a->epi == STDIFF_EPI_GATE_RES)
@@ -1170,6 +1331,15 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
     // four-phase gemm256p it was derived from (A/B timing), 4 forces the default kernel for any shape
     bool variant_q = forced != 3 && ((double)a->M + 256) * a->lda < 2.0e9 && ((double)a->N + 256) * a->ldw < 2.0e9;   // 32-bit DMA offsets
     if (bf && forced == 4) tile = 3;
+    if (a->stats_out) {        // produced by the gate-residual tile epilogue of the persistent kernel only
+        STDIFF_CHECK_ARG(a->epi == STDIFF_EPI_GATE_RES && bf && !a->C2 && !ak && !wk);
+        if (a->N % 256) return STDIFF_ERR_SHAPE;
+        if (!vec) return STDIFF_ERR_ALIGN;
+    }
+    if (lnmod || a->stats_out) {
+        if (!variant_q || forced == 3) return STDIFF_ERR_SHAPE;     // operands beyond the 32-bit offsets of the LDS-DMA kernel
+        tile = 3;
+    }
     const int bm = tile == 1 ? BM : 256, bn = tile == 1 ? BN : 256;
     p.tiles_m = cdiv(a->M, bm);
     p.tiles_n = cdiv(a->N, bn);
@@ -1225,8 +1395,12 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
         STDIFF_LAUNCH128(float);
     else if (tile == 1)
         STDIFF_LAUNCH128(bf16_t);
+    else if (variant_q && lnmod)
+        hipLaunchKernelGGL(gemm256q_kernel<1>, grid, block, 0, (hipStream_t)stream, p);
+    else if (variant_q && a->stats_out)
+        hipLaunchKernelGGL(gemm256q_kernel<2>, grid, block, 0, (hipStream_t)stream, p);
     else if (variant_q)
-        hipLaunchKernelGGL(gemm256q_kernel, grid, block, 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(gemm256q_kernel<0>, grid, block, 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(gemm256p_kernel, grid, block, 0, (hipStream_t)stream, p);
     if (p.ksplit > 1) {

@@ -33,7 +33,12 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
             for (int j = 0; j < 4; ++j) { float d = v[i][j] - mean; q += d * d; }
         }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)H + 1e-6f);
+    const float m2 = wave_sum(q);
+    const float rstd = rsqrtf(m2 / (float)H + 1e-6f);
+    if (y == nullptr) {                             // statistics only (stdiff_row_stats): (mean, M2) pairs
+        if (lane == 0) { mean_out[2 * row] = mean; mean_out[2 * row + 1] = m2; }
+        return;
+    }
     if (mean_out && lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
     // (requesting shift / scale together with x, ahead of the two reductions, was slower: 35 against 31.5 us at
     // 20 000 x 1024 -- the 16 extra live registers cost more occupancy than the hidden latency is worth)
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
         if (c < H) {
             f32x4 a = ld4(sh + c), b = ld4(sc + c), o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * (1.0f + b[j]) + a[j];
+            for (int j = 0; j < 4; ++j) o[j] = ln_mod_apply(v[i][j], mean, rstd, b[j], a[j]);
             st4(yr + c, o);
         }
     }
@@ -189,6 +194,15 @@ extern "C" int stdiff_ln_modulate(const float* x, int ldx, const void* shift, co
     if (!mb && !ob) return launch_ln<float, float>(x, ldx, shift, scale, ldmod, y, ldy, mean, rstd, R, H, st);
     if (!mb && ob) return launch_ln<float, bf16_t>(x, ldx, shift, scale, ldmod, y, ldy, mean, rstd, R, H, st);
     return launch_ln<bf16_t, float>(x, ldx, shift, scale, ldmod, y, ldy, mean, rstd, R, H, st);
+}
+
+extern "C" int stdiff_row_stats(const float* x, int ldx, float* parts, int R, int H, void* stream) {
+    STDIFF_CHECK_ARG(x && parts && R >= 0 && H > 0);
+    if (R == 0) return STDIFF_OK;
+    if (H % 4) return STDIFF_ERR_SHAPE;
+    if (ldx % 4 || !al16(x)) return STDIFF_ERR_ALIGN;
+    // the same kernel as stdiff_ln_modulate (same reduction order, same bits) with the output pass switched off
+    return launch_ln<bf16_t, bf16_t>(x, ldx, nullptr, nullptr, 0, nullptr, 0, parts, nullptr, R, H, (hipStream_t)stream);
 }
 
 extern "C" int stdiff_silu_cond(const float* temb, const int32_t* t_index, const float* ycond, int ldy, void* s,

@@ -55,6 +55,20 @@ class PackedWeights:
                 kp = self.Gp if name in ("in_layer.0.weight", "cond_layer.0.weight") else p.shape[1]
                 self.w[name] = torch.empty((p.shape[0], kp), device=dev, dtype=self.tdt)
         self.freqs = sinusoid_freqs(dev)
+        # fused-LN form of the adaLN projections (16-bit operands, STDIFF_FUSED_LN=0 switches it off): per block the
+        # (shift, scale) rows of each LayerNorm in 256-row tiles [128 shift | 128 scale] and the two gate slices as one
+        # [2H, H] matrix; made from the packed operands on first use and whenever they changed
+        self.fused = None
+        self.fused_stale = True
+        if dtype != F32 and H % 128 == 0 and os.environ.get("STDIFF_FUSED_LN", "1") == "1":
+            self.fused = {}
+            for k in list(range(depth)) + ["f"]:
+                for part in (("ln1", "ln2", "gate") if k != "f" else ("ln",)):
+                    self.fused[f"{k}.{part}_w"] = torch.empty((2 * H, H), device=dev, dtype=self.tdt)
+                    self.fused[f"{k}.{part}_b"] = torch.empty((2 * H,), device=dev, dtype=torch.float32)
+            t = torch.arange(H // 128, device=dev).repeat_interleave(256) * 128
+            j = torch.arange(256, device=dev).repeat(H // 128)
+            self._tile_perm = t + (j % 128) + (j // 128) * H      # row of [shift(H) ; scale(H)] behind fused row i
         self.refresh()
         self._build_struct()
 
@@ -62,6 +76,29 @@ class PackedWeights:
         for name, buf in self.w.items():
             if name not in skip:
                 ops.pack_rows(self.params[name].detach(), buf.shape[1], buf.dtype, out=buf)
+        self.fused_stale = True
+
+    def ensure_fused(self):
+        """Bring the fused-LN operand copies up to date with the packed adaLN operands (no-op when current)."""
+        if self.fused is None or not self.fused_stale:
+            return
+        H, perm = self.H, self._tile_perm
+        with torch.no_grad():
+            for k in list(range(self.depth)) + ["f"]:
+                name = f"blks.{k}.adaLN_modulation.1" if k != "f" else "out_layer.adaLN_modulation.1"
+                W, b = self.w[name + ".weight"], self.b(name + ".bias")
+                if k == "f":
+                    torch.index_select(W, 0, perm, out=self.fused["f.ln_w"])
+                    torch.index_select(b, 0, perm, out=self.fused["f.ln_b"])
+                    continue
+                for part, lo in (("ln1", 0), ("ln2", 3 * H)):
+                    torch.index_select(W[lo:lo + 2 * H], 0, perm, out=self.fused[f"{k}.{part}_w"])
+                    torch.index_select(b[lo:lo + 2 * H], 0, perm, out=self.fused[f"{k}.{part}_b"])
+                self.fused[f"{k}.gate_w"][:H].copy_(W[2 * H:3 * H])
+                self.fused[f"{k}.gate_w"][H:].copy_(W[5 * H:6 * H])
+                self.fused[f"{k}.gate_b"][:H].copy_(b[2 * H:3 * H])
+                self.fused[f"{k}.gate_b"][H:].copy_(b[5 * H:6 * H])
+        self.fused_stale = False
 
     def adopt(self, views):
         """Replace operand buffers by caller-owned tensors of the same shape and dtype (the training engine's flat
@@ -69,6 +106,7 @@ class PackedWeights:
         for name, t in views.items():
             assert t.shape == self.w[name].shape and t.dtype == self.w[name].dtype and t.is_contiguous()
             self.w[name] = t
+        self.fused_stale = True
         self._build_struct()
 
     def b(self, name):
@@ -83,6 +121,10 @@ class PackedWeights:
                          ("ada", "adaLN_modulation.1")):
                 setattr(bw, f + "_w", ptr(self.w[pre + n + ".weight"]))
                 setattr(bw, f + "_b", ptr(self.b(pre + n + ".bias")))
+            if self.fused is not None:
+                for f in ("ln1", "ln2", "gate"):
+                    setattr(bw, f + "_w", ptr(self.fused[f"{k}.{f}_w"]))
+                    setattr(bw, f + "_b", ptr(self.fused[f"{k}.{f}_b"]))
         s = L.DitWeights()
         s.dtype, s.G, s.Gp, s.H, s.heads, s.depth = c_dtype(self.dtype), self.G, self.Gp, self.H, self.heads, self.depth
         s.in_w, s.in_b = ptr(self.w["in_layer.0.weight"]), ptr(self.b("in_layer.0.bias"))
@@ -90,6 +132,8 @@ class PackedWeights:
         s.fada_w = ptr(self.w["out_layer.adaLN_modulation.1.weight"])
         s.fada_b = ptr(self.b("out_layer.adaLN_modulation.1.bias"))
         s.blocks = C.cast(self.blocks, C.POINTER(L.BlockWeights))
+        if self.fused is not None:
+            s.lnf_w, s.lnf_b = ptr(self.fused["f.ln_w"]), ptr(self.fused["f.ln_b"])
         self.struct = s
 
 
@@ -111,28 +155,38 @@ class Workspace:
         self.R, self.chunk_lens = R, list(chunk_lens)
         cu = np.concatenate([[0], np.cumsum(chunk_lens)]).astype(np.int32)
         self.cu_rows = torch.from_numpy(cu).to(dev)
+        # fused-LN form (stdiff_hip.h, STDIFF_EPI_LN_MOD): the [R, 6H] modulation matrix is never materialised; row
+        # statistics and the two gates of a block take its place.  The owner of shared buffers decides for its aliases.
+        # Every workspace of a model takes the same form (the two agree to rounding, not to the bit, when H % 256 == 0).
+        self.fused = share.fused if share is not None else pw.fused is not None
+        bufs = [b for b in self.BUFS if not (self.fused and b[0] in ("mod", "fmod"))]
+        if self.fused:
+            bufs += [("gates", 2, False), ("ln_parts", 0, True)]
+        self.mod = self.fmod = self.gates = self.ln_parts = None
+        nparts = max(1, H // 256)            # partial row moments per row (stdiff_hip.h, stdiff_gemm_args)
         if share is not None:
             assert share.R >= R
-            for name, width, f32 in self.BUFS:
+            for name, width, f32 in bufs:
                 setattr(self, name, getattr(share, name)[:R])
             self.eps = share.eps[:R]
         else:
             # ONE allocation for the whole set, carved at 2 MiB boundaries: a single large hipMalloc instead of nine
-            specs = [(name, width * H, torch.float32 if f32 else tdt) for name, width, f32 in self.BUFS]
+            specs = [(name, width * H if width else 2 * nparts, torch.float32 if f32 else tdt) for name, width, f32 in bufs]
             specs.append(("eps", pw.G, torch.float32))
             sizes = [ops.round_up(R * cols * torch.empty((), dtype=dt).element_size(), 2 << 20) for _, cols, dt in specs]
             self.arena = torch.empty(sum(sizes), device=dev, dtype=torch.uint8)
             off = 0
             for (name, cols, dt), nbytes in zip(specs, sizes):
                 es = torch.empty((), dtype=dt).element_size()
-                setattr(self, name, self.arena[off:off + R * cols * es].view(dt).view(R, cols))
+                t = self.arena[off:off + R * cols * es].view(dt)
+                setattr(self, name, t.view(R, cols))
                 off += nbytes
         self._xp = None
         self._pw = pw
         s = L.DitWorkspace()
         s.R, s.n_chunks, s.max_chunk_rows = R, len(chunk_lens), int(max(chunk_lens)) if chunk_lens else 0
         s.cu_rows = ptr(self.cu_rows)
-        for n in ("h", "mod", "xn", "qkv", "o", "u", "fmod"):
+        for n in ("h", "mod", "xn", "qkv", "o", "u", "fmod", "ln_parts", "gates"):
             setattr(s, n, ptr(getattr(self, n)))
         self.struct = s
 
@@ -221,6 +275,8 @@ class DenoiserEngine:
         xp = ws.xp if xp is None else xp
         s = ws.s if s is None else s
         assert xp.shape == (ws.R, self.pw.Gp) and xp.is_contiguous() and s.shape == (ws.R, self.pw.H)
+        if ws.fused:
+            self.pw.ensure_fused()
         check(lib_for(xp).stdiff_dit_forward(C.byref(self.pw.struct), C.byref(ws.struct), ptr(xp), ptr(s),
                                        ptr(ws.eps), ws.eps.stride(0), stream()))
         return ws.eps

@@ -23,10 +23,15 @@ class _Act(_Holder):
     pass
 
 
+class _Linear(nn.Linear):
+    """nn.Linear as a parameter holder (same state-dict keys, same default init call sites as the reference's)."""
+
+    def forward(self, *a, **k):       # a class-level override: a bound method stored ON the instance would be a
+        raise RuntimeError("stdiff_amd modules are parameter holders; call DiT_stDiff.forward")   # reference cycle
+
+
 def _linear(i, o):
-    lin = nn.Linear(i, o, bias=True)
-    lin.forward = _Holder.forward.__get__(lin)
-    return lin
+    return _Linear(i, o, bias=True)
 
 
 def _seq(*mods):

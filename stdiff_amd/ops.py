@@ -13,7 +13,7 @@ def round_up(a, b):
 
 
 def gemm(A, W, bias=None, out=None, out_dtype=None, epi=L.EPI_BIAS, gate=None, res=None, out2=None, M=None,
-         workspace=None, a_kmajor=False, w_kmajor=False, static_scratch=False):
+         workspace=None, a_kmajor=False, w_kmajor=False, static_scratch=False, ln_parts=None, stats_out=None):
     """out[M,N] = epi(A[M,K] @ W[N,K]^T + bias). A/W: same dtype (fp32 or bf16), K-contiguous rows -- or, with
     a_kmajor / w_kmajor, given as [K, M] / [K, N] (K rows; need not be a multiple of the K-slab).
     static_scratch=True: stdiff_gemm_static_scratch -- split-K partials in the library's own device array, nothing is
@@ -35,7 +35,7 @@ def gemm(A, W, bias=None, out=None, out_dtype=None, epi=L.EPI_BIAS, gate=None, r
     M = (A.shape[1] if a_kmajor else A.shape[0]) if M is None else M
     N = W.shape[1] if w_kmajor else W.shape[0]
     if out is None:
-        out = torch.empty((M, N), device=A.device, dtype=out_dtype or A.dtype)
+        out = torch.empty((M, N // 2 if epi == L.EPI_LN_MOD else N), device=A.device, dtype=out_dtype or A.dtype)
     a = L.GemmArgs()
     a.M, a.N, a.K = M, N, K
     a.a_layout, a.w_layout, a.k_valid = int(a_kmajor), int(w_kmajor), k_valid
@@ -50,6 +50,14 @@ def gemm(A, W, bias=None, out=None, out_dtype=None, epi=L.EPI_BIAS, gate=None, r
         a.res, a.ldres = ptr(res), res.stride(0)
     if out2 is not None:
         a.C2, a.ldc2 = ptr(out2), out2.stride(0)
+    if ln_parts is not None:           # EPI_LN_MOD: partial row moments of `res`, fp32 [M, parts, 2] (row_stats: 1 part)
+        require_gpu(ln_parts)
+        assert ln_parts.dtype == torch.float32 and ln_parts.is_contiguous() and ln_parts.shape[0] >= M
+        a.ln_parts, a.ln_nparts = ptr(ln_parts), ln_parts.shape[1]
+    if stats_out is not None:          # gated-residual epilogue also writes the partial row moments of its output
+        require_gpu(stats_out)
+        assert stats_out.dtype == torch.float32 and stats_out.is_contiguous() and stats_out.shape == (M, N // 256, 2)
+        a.stats_out = ptr(stats_out)
     if workspace is not None:          # fp32 scratch for split-K (small outputs with a long K)
         a.workspace, a.workspace_bytes = ptr(workspace), workspace.numel() * workspace.element_size()
     lb = lib_for(A, W, out, gate, out2)
@@ -90,6 +98,18 @@ def ln_modulate(x, shift, scale, out=None, out_dtype=None, mean=None, rstd=None)
     check(lib_for(shift, out).stdiff_ln_modulate(ptr(x), x.stride(0), ptr(shift), ptr(scale), shift.stride(0), dt_of(shift),
                                    ptr(out), out.stride(0), dt_of(out), ptr(mean), ptr(rstd), R, H, stream()))
     return out
+
+
+def row_stats(x, parts=None):
+    """Row moments of x fp32 [R, H] as ONE part per row: fp32 [R, 1, 2] = (mean, sum of squared deviations) -- the
+    statistics of LayerNorm(eps 1e-6, biased variance) in the form the LN_MOD GEMM epilogue reads."""
+    require_gpu(x, parts)
+    R, H = x.shape
+    if parts is None:
+        parts = torch.empty((R, 1, 2), device=x.device, dtype=torch.float32)
+    assert parts.dtype == torch.float32 and parts.is_contiguous() and parts.numel() >= 2 * R
+    check(lib().stdiff_row_stats(ptr(x), x.stride(0), ptr(parts), R, H, stream()))
+    return parts
 
 
 def silu_cond(ycond, temb=None, t_index=None, out=None, out_dtype=torch.float32):

@@ -388,6 +388,7 @@ class TrainEngine(TrainCore):
         group the bucketed all-reduce is issued from the host between backward segments."""
         C = x.shape[0]
         dev = self.device
+        self.pw.fused_stale = True       # the optimizer kernel rewrites the operand mirror without going through refresh()
         if use_graph and self.world == 1:
             return self._step_graph(x, x_cond, noise, timesteps)
         a = self.acts(C)

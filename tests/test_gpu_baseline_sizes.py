@@ -258,7 +258,7 @@ def test_config4_fp32_vs_bf16_full_loop():
     assert g16["PCC"].min() > 0.9999 and g16["cosine"].min() > 0.9999 and g16["PCC"].min() >= gm["PCC"].min()
 
 
-def test_config2_shape_depth6_training_iteration_against_oracle():
+def test_config2_shape_depth6_training_iteration_against_oracle(progress):
     """configs[2]'s per-rank step at the FULL model: 512 cells x 2000 genes, hidden 2048, depth 6 (478.6 M parameters,
     1.9 GB of gradients -- the data-parallel bucket payload), fp32: loss, gradient norm, every gradient and the
     parameters after clip + AdamW against the oracle's autograd (about half a minute of host time)."""
@@ -274,8 +274,10 @@ def test_config2_shape_depth6_training_iteration_against_oracle():
     x = torch.from_numpy(st)
     xc = torch.from_numpy(st * mask * 1.0).float()
     tb = O.make_tables(T, schedule="cosine")
+    progress("configs[2] depth 6: model built, oracle autograd running")
     loss_r, grads, _ = O.loss_and_grads(p, tb, x, xc, noise, tt, mask, heads, depth)
     gn_r = float(sum(g.double().pow(2).sum() for g in grads.values()) ** 0.5)
+    progress("configs[2] depth 6: oracle done")
     te = TrainEngine(m, lr=1e-4, diffusion_step=T, mask=mask)
     assert len(te.buckets) == depth + 2 and te.total * 4 > 1.9e9
     loss, gn = te.step(x.to(DEV), xc.to(DEV), noise=noise.to(DEV), timesteps=tt.to(DEV))
@@ -285,56 +287,3 @@ def test_config2_shape_depth6_training_iteration_against_oracle():
     gscale = max(float(g.abs().max()) for g in grads.values())
     for n, g in grads.items():
         assert float((te.g[n].cpu() - g).abs().max()) < 1e-4 * gscale, n
-
-
-def test_config4_five_folds_full_size_tolerance_sweep():
-    """configs[4] at its full size: 10 000 spots x 500 genes, hidden 1024, chunks of 512 (the last one 272 rows), all
-    FIVE gene folds through the driver flow (per-fold weights loaded as checkpoints, then the whole 1000-step reverse loop) in fp32,
-    bf16 and fp16 with the same weights and the same Philox noise.  Reported and asserted per fold on the imputed
-    (held-out) genes: per-gene Pearson / cosine of each 16-bit result against the fp32 one.  The oracle pins the fp32
-    run itself: one chunk per fold, teacher-forced on the run's own final state, within 1e-5 (max-norm)."""
-    from stdiff_amd import engine as E
-    from stdiff_amd.driver import diffusion_impute, fold_mask, kfold_gene_splits
-    from stdiff_amd.metrics import gene_metrics
-    from stdiff_amd.model.stDiff_model import DiT_stDiff
-    N, G, H, depth, heads, B, T = 10000, 500, 1024, 6, 16, 512, 1000
-    seq = O.synth_expression(4096, G, 21)
-    st = O.synth_expression(N, G, 22)
-    import tempfile
-    with tempfile.TemporaryDirectory() as ck:
-        kw = dict(lr=0.00016046744893538737, depth=depth, num_epoch=2, diffusion_step=T, batch_size=B, hidden_size=H,
-                  head=heads, device=torch.device(DEV), save_dir=ck, sample_seed=4242)
-        # a model two epochs from the reference initialisation still outputs ~0 (zero-initialised adaLN / output
-        # layers), which would make every precision agree trivially: the folds load re-randomised weights through the
-        # driver's checkpoint path instead (training at this shape: test_config2_* and tests/test_gpu_train.py)
-        for k in range(5):
-            torch.save(O.make_params(G, H, depth, 60 + k), f"{ck}/stDiff{k + 1}.pt")
-        res = {dt: diffusion_impute(seq, st, compute_dtype=dt, **kw) for dt in ("fp32", "bf16", "fp16")}
-        splits = kfold_gene_splits(G, 5, 0)
-        for k, (_, te) in enumerate(splits):
-            ref = torch.from_numpy(res["fp32"][:, te]).to(DEV)
-            line = [f"configs[4] fold {k + 1} ({len(te)} held-out genes):"]
-            for dt, floor in (("bf16", 0.999), ("fp16", 0.9999)):
-                gm = gene_metrics(torch.from_numpy(res[dt][:, te]).to(DEV), ref, js=False, spcc=False)
-                a, b = res[dt][:, te].astype(np.float64), res["fp32"][:, te].astype(np.float64)
-                line.append(f"{dt} Pearson min {gm['PCC'].min():.6f} median {np.median(gm['PCC']):.7f} cosine min "
-                            f"{gm['cosine'].min():.6f} rel-l2 {np.linalg.norm(a - b) / np.linalg.norm(b):.2e};")
-                assert gm["PCC"].min() > floor and gm["cosine"].min() > floor, (k, dt)
-            print(" ".join(line))
-            assert np.isfinite(res["fp32"]).all()
-            # the oracle on one chunk of this fold's model (the ragged last chunk for fold 5), teacher-forced
-            sd = torch.load(f"{ck}/stDiff{k + 1}.pt", map_location="cpu", weights_only=True)
-            m = DiT_stDiff(G, H, depth, 'dit', heads, 6, compute_dtype="fp32")
-            m.load_state_dict(sd)
-            m = m.to(DEV).eval()
-            lo, hi = (19 * B, N) if k == 4 else (k * B, (k + 1) * B)
-            mask = fold_mask(G, te)
-            x_c = torch.from_numpy((res["fp32"][lo:hi] * 2 - 1).astype(np.float32))     # a state of the right scale
-            y_c = torch.from_numpy(((st[lo:hi] * mask) * 2 - 1).astype(np.float32))
-            tt = torch.full((hi - lo,), 37 * (k + 1), dtype=torch.int64)
-            with torch.no_grad():
-                got = m(x_c, tt, y_c).cpu()
-                want = O.dit_forward({n: v.float() for n, v in sd.items()}, x_c, tt, y_c, heads, depth)
-            e = relerr(got, want)
-            print(f"   fp32 denoiser call on chunk rows {lo}:{hi} vs oracle: {e:.2e}")
-            assert e < FP32_TOL, k

@@ -71,7 +71,7 @@ def test_config3_full_size_properties_fp16():
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "fp16"])
-def test_config3_chunks_against_oracle(dtype):
+def test_config3_chunks_against_oracle(dtype, progress):
     """Teacher-forced denoiser call over the full 1 M-row matrix; the oracle evaluates five of its 1954 chunks, and
     the fused scheduler step of those chunks is checked bit-for-bit-tolerance against the oracle's with injected z."""
     from stdiff_amd import engine as E
@@ -97,7 +97,7 @@ def test_config3_chunks_against_oracle(dtype):
             ref = O.dit_forward(p, x_c, torch.full((hi - lo,), t, dtype=torch.int64), gt_c, HEADS, DEPTH)
             e = relerr(eps[lo:hi], ref)
             worst = max(worst, e)
-            print(f"configs[3] {dtype} chunk {k} ({hi - lo} rows): eps rel err {e:.3e}")
+            progress(f"configs[3] {dtype} chunk {k} ({hi - lo} rows): eps rel err {e:.3e}")
             assert e < tol, k
             if dtype == "fp32" and k in (0, 1953):
                 z = torch.randn(hi - lo, G, generator=torch.Generator().manual_seed(k))

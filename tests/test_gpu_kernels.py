@@ -438,3 +438,53 @@ def test_masked_mse(ops):
     d = torch.empty(R, G, device=DEV)
     ops.masked_mse(pred.to(DEV), noise.to(DEV), mask.to(DEV), l, dpred=d)
     assert abs(float(l) - float(loss)) < 1e-6 and relerr(d, p.grad) < 1e-6
+
+
+@pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [512, 2048 + 37])
+def test_gemm_ln_mod_epilogue_equals_unfused(tdt, M):
+    """STDIFF_EPI_LN_MOD: the adaLN projection whose epilogue applies the LayerNorm + modulate it feeds must give, bit
+    for bit, what the plain GEMM into a 16-bit [M, 2H] buffer followed by stdiff_ln_modulate gives (and that pair is
+    checked against torch below)."""
+    from stdiff_amd import _lib as L
+    from stdiff_amd import ops
+    H, K = 256, 128
+    g = torch.Generator().manual_seed(M)
+    s = torch.randn(M, K, generator=g).to(DEV).to(tdt)
+    W = (torch.randn(2 * H, K, generator=g) * K ** -0.5).to(DEV).to(tdt)      # rows [shift(H) ; scale(H)]
+    b = torch.randn(2 * H, generator=g).to(DEV)
+    h = (torch.randn(M, H, generator=g) * 1.7 + 0.3).to(DEV)
+    # unfused: mod = s W^T + b (16-bit), xn = LN(h) * (1 + scale) + shift
+    mod = ops.gemm(s, W, b, out_dtype=tdt)
+    want = ops.ln_modulate(h, mod[:, :H], mod[:, H:], out_dtype=tdt)
+    # fused: rows permuted into 256-row tiles [128 shift | 128 scale]
+    t = torch.arange(H // 128, device=DEV).repeat_interleave(256) * 128
+    j = torch.arange(256, device=DEV).repeat(H // 128)
+    perm = t + (j % 128) + (j // 128) * H
+    parts = ops.row_stats(h)                              # [M, 1, 2] = (mean, M2): the LN kernel's own reduction
+    got = torch.full((M, H), float("nan"), device=DEV, dtype=tdt)
+    Wp, bp = W[perm].contiguous(), b[perm].contiguous()
+    ops.gemm(s, Wp, bp, out=got, epi=L.EPI_LN_MOD, res=h, ln_parts=parts)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    ref = torch.nn.functional.layer_norm(h, (H,), eps=1e-6) * (1 + mod[:, H:].float()) + mod[:, :H].float()
+    assert relerr(got, ref) < (1e-2 if tdt == torch.bfloat16 else 2e-3)
+    assert relerr(parts[:, 0, 0], h.mean(1)) < 1e-5 and relerr(parts[:, 0, 1], h.var(1, unbiased=False) * H) < 1e-5
+    with pytest.raises(ValueError):                    # N must be a multiple of 256
+        ops.gemm(s, Wp[:384].contiguous(), bp[:384].contiguous(), out=got, epi=L.EPI_LN_MOD, res=h, ln_parts=parts)
+    # the statistics handed over by the epilogue that WRITES the residual stream (stats_out of a gated-residual GEMM:
+    # one (mean_p, M2_p) pair per row and 256-column tile) give the same LayerNorm to rounding
+    A2 = torch.randn(M, K, generator=g).to(DEV).to(tdt)
+    W2 = (torch.randn(H, K, generator=g) * K ** -0.5).to(DEV).to(tdt)
+    gate = torch.randn(M, H, generator=g).to(DEV).to(tdt)
+    h2, h2b = torch.empty(M, H, device=DEV), torch.empty(M, H, device=DEV)
+    so = torch.full((M, H // 256, 2), float("nan"), device=DEV)
+    ops.gemm(A2, W2, None, out=h2, epi=L.EPI_GATE_RES, gate=gate, res=h, stats_out=so)
+    ops.gemm(A2, W2, None, out=h2b, epi=L.EPI_GATE_RES, gate=gate, res=h)
+    assert torch.equal(h2, h2b)                           # producing the statistics does not touch the output
+    cols = h2.view(M, H // 256, 256)
+    assert relerr(so[:, :, 0], cols.mean(2)) < 1e-5 and relerr(so[:, :, 1], cols.var(2, unbiased=False) * 256) < 1e-4
+    got2 = torch.empty((M, H), device=DEV, dtype=tdt)
+    ops.gemm(s, Wp, bp, out=got2, epi=L.EPI_LN_MOD, res=h2, ln_parts=so)
+    want2 = ops.ln_modulate(h2, mod[:, :H], mod[:, H:], out_dtype=tdt)
+    assert relerr(got2, want2) < (8e-3 if tdt == torch.bfloat16 else 1e-3)          # one 16-bit ulp of the largest value

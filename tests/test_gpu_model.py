@@ -447,3 +447,53 @@ def test_errors_and_quirks():
     with pytest.raises(NotImplementedError):
         sample_stDiff(m, [], NoiseScheduler(10), mask=np.ones(40), gt=np.zeros((8, 40)), sample_shape=(8, 40),
                       is_condi=True, model_pred_type='v')
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("H", [128, 256])
+def test_fused_ln_forward_against_unfused(dtype, H, monkeypatch):
+    """The fused-LN form of the denoiser forward (LayerNorm + modulate as the epilogue of the adaLN GEMM, no [R, 6H]
+    modulation matrix) against the plain form (STDIFF_FUSED_LN=0).  H = 128: every LayerNorm's statistics come from the
+    statistics pass, and eps is bit-identical.  H = 256: the gated-residual epilogues hand over partial row moments
+    (another, equally exact summation order), and eps agrees to the rounding of one 16-bit operand.  In both cases a
+    chunk run alone equals the chunk inside a larger run bit for bit (every workspace of a model takes the same form)."""
+    from stdiff_amd import engine as E
+    from stdiff_amd.model.stDiff_model import DiT_stDiff
+    from stdiff_amd.model.stDiff_scheduler import NoiseScheduler
+    G, depth, heads = 72, 2, 4
+    lens = [512] * 4 + [512, 300, 45]                      # 2905 rows, ragged
+    R = sum(lens)
+    p = O.make_params(G, H, depth, 77)
+    x = torch.randn(R, G, generator=torch.Generator().manual_seed(1)).to(DEV)
+    y = torch.randn(R, G, generator=torch.Generator().manual_seed(2)).to(DEV)
+    t = torch.full((R,), 321, dtype=torch.int64, device=DEV)
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("STDIFF_FUSED_LN", fused)
+        m = DiT_stDiff(G, H, depth, 'dit', heads, 6, compute_dtype=dtype)
+        m.load_state_dict(p)
+        m = m.to(DEV).eval()
+        eng = m.engine()
+        assert (eng.pw.fused is not None) == (fused == "1")
+        with torch.no_grad():
+            outs[fused] = eng.forward(x, t, y, chunk_lens=lens).clone()
+            assert eng.workspace(lens).fused == (fused == "1")
+        if fused == "1":
+            mask = torch.from_numpy(O.kfold_mask(G, 0)).to(DEV)
+            ns = NoiseScheduler(50, beta_schedule="cosine")
+            with torch.no_grad():
+                full = E.ReverseSampler(eng, ns, lens, y, y, mask, seed=3)
+                full.init()
+                res = full.run([49, 48, 47]).clone()
+                one = E.ReverseSampler(eng, ns, lens[5:6], y[2560:2860], y[2560:2860], mask, seed=3, row_offset=2560, lane=5)
+                assert one.slabs[0][2].fused
+                one.init()
+                assert torch.equal(one.run([49, 48, 47]), res[2560:2860])
+    if H % 256:
+        assert torch.equal(outs["1"], outs["0"])
+    else:
+        e = relerr(outs["1"], outs["0"])
+        print(f"fused-LN vs plain forward, H={H} {dtype}: {e:.2e}")
+        assert e < (1e-2 if dtype == "bf16" else 1.5e-3)
+    ref = O.denoise_chunked(p, x[:512].cpu(), 321, y[:512].cpu(), 512, heads, depth)
+    assert relerr(outs["1"][:512], ref) < (3e-2 if dtype == "bf16" else 1e-3)

@@ -275,6 +275,19 @@ def test_normal_train_stdiff_reduces_loss():
 # ---------------------------------------------------------------- data-parallel TrainEngine, 2 ranks sharing cuda:0
 def _ddp_worker(rank, world, port, golden_dir, q, backend="gloo"):
     import torch.distributed as dist
+    import faulthandler
+    faulthandler.enable()
+    trace = None
+    if os.environ.get("STDIFF_TEST_DUMP"):               # stack of a stuck worker after that many seconds
+        faulthandler.dump_traceback_later(int(os.environ["STDIFF_TEST_DUMP"]), exit=True)
+        trace = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"ddp_worker{rank}.log"), "a")
+
+    def stage(msg):
+        if trace:
+            import time
+            trace.write(f"{time.time():.1f} rank {rank}: {msg}\n")
+            trace.flush()
+    stage("start")
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     DEV = f"cuda:{rank}" if backend == "nccl" else "cuda:0"          # RCCL: one GPU per rank; gloo: both on cuda:0
     torch.cuda.set_device(DEV)
@@ -287,18 +300,22 @@ def _ddp_worker(rank, world, port, golden_dir, q, backend="gloo"):
         g6 = np.load(os.path.join(golden_dir, "g6_train.npz"))
         g7 = np.load(os.path.join(golden_dir, "g7_ddp.npz"))
         C, G, H, depth, heads, seed, T = [int(v) for v in g6["cfg"]]
+        stage("process group up")
         m, _ = build(G, H, depth, heads, seed, "fp32")
         m = m.to(DEV)
+        stage("model on device")
         if rank == 1:                                    # rank 0's parameters must win (broadcast at construction)
             with torch.no_grad():
                 m.blks[0].mlp.fc1.weight.add_(1.0)
         te = TrainEngine(m, lr=float(g6["lr"][0]), diffusion_step=T, mask=g6["mask"])
         assert te.world == world and te.async_buckets == (backend == "nccl")
+        stage("engine built (parameters broadcast)")
         x = torch.from_numpy(g6["x"])[rank * C:(rank + 1) * C].contiguous().to(DEV)
         xc = torch.from_numpy(g6["x_cond"])[rank * C:(rank + 1) * C].contiguous().to(DEV)
         loss, gn = te.step(x, xc, noise=torch.from_numpy(g6["noise"][rank]).to(DEV),
                            timesteps=torch.from_numpy(g6["timesteps"][rank]).to(DEV))
         torch.cuda.synchronize()
+        stage("step done")
         assert abs(float(gn) - g7["gnorm"][0]) < 1e-4 * g7["gnorm"][0], (float(gn), g7["gnorm"][0])
         sd = m.state_dict()
         worst = 0.0
@@ -341,7 +358,7 @@ def test_ddp_train_step_two_ranks_golden(golden_dir, backend):
     procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, golden_dir, q, backend)) for r in range(2)]
     for p_ in procs:
         p_.start()
-    res = [q.get(timeout=240) for _ in procs]
+    res = [q.get(timeout=int(os.environ.get("STDIFF_TEST_DUMP", "120")) + 30) for _ in procs]      # stays under the box's 3-minute silence limit
     for p_ in procs:
         p_.join(60)
     for rank, status, info in res:
