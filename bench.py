@@ -60,7 +60,16 @@ def gemm_launches(eng, ws):
     out = []
 
     def add(A, W, b, o, **kw):
-        out.append((R, W.shape[0], W.shape[1], lambda: ops.gemm(A, W, b, out=o, **kw)))
+        # algorithmic bytes of the launch: both operands, the output and the epilogue's side inputs, each once
+        nb = A[:, :W.shape[1]].numel() * A.element_size() + W.numel() * W.element_size() + o.numel() * o.element_size()
+        for side in ("gate", "res"):
+            if kw.get(side) is not None:
+                t = kw[side] if kw.get("epi") != L.EPI_LN_MOD else kw[side][:, :W.shape[0] // 2]
+                nb += t.numel() * t.element_size()
+        for side in ("ln_parts", "stats_out"):
+            if kw.get(side) is not None:
+                nb += kw[side].numel() * 4
+        out.append((R, W.shape[0], W.shape[1], lambda: ops.gemm(A, W, b, out=o, **kw), nb))
     add(ws.xp, pw.w["in_layer.0.weight"], pw.b("in_layer.0.bias"), ws.h)
     if ws.fused:
         pw.ensure_fused()
@@ -97,16 +106,17 @@ def measure_gemm_roofline(eng, ws, dtype, reps=3):
     launches of one denoiser forward of a full row slab (the unit the timed loop launches: 45 in the fused-LN form,
     33 in the plain one, the same 2MNK in total); achieved = algorithmic FLOPs (2MNK) / time."""
     launches = gemm_launches(eng, ws)
-    flops = sum(2.0 * m * n * k for m, n, k, _ in launches)
+    flops = sum(2.0 * m * n * k for m, n, k, _, _ in launches)
+    alg_bytes = sum(nb for *_, nb in launches) / len(launches)
     for buf in (ws.xp, ws.s, ws.xn, ws.o, ws.u, ws.h, ws.gates if ws.fused else ws.mod):
         buf.normal_(0, 0.5)
-    for _, _, _, f in launches:
+    for _, _, _, f, _ in launches:
         f()
     torch.cuda.synchronize()
     total_ms = 0.0
     for _ in range(reps):
         evs = []
-        for _, _, _, f in launches:
+        for _, _, _, f, _ in launches:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             f()
@@ -117,14 +127,17 @@ def measure_gemm_roofline(eng, ws, dtype, reps=3):
     avg_ms = total_ms / (reps * len(launches))
     achieved = flops / len(launches) / (avg_ms * 1e-3) / 1e12
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "gemm_traffic.json")      # PMC-derived HBM bytes per launch, if collected
-    if os.path.isfile(tfile):
-        rec = json.load(open(tfile))
-        if rec.get("rows_per_launch") == ws.R:                        # collected at this slab size only
-            traffic = rec.get(dtype)
+    # PMC-derived HBM bytes per launch (tools/pmc_traffic.py; the copy at the root travels to the GPU box, profiles/ does not)
+    for tfile in (os.path.join(ROOT, "bench_traffic.json"), os.path.join(ROOT, "profiles", "gemm_traffic.json")):
+        if traffic is None and os.path.isfile(tfile):
+            rec = json.load(open(tfile))
+            # collected at this slab size and for this launch sequence only
+            if rec.get("rows_per_launch") == ws.R and rec.get("launches_per_slab", 33) == len(launches):
+                traffic = rec.get(dtype)
     return {"bound": "mfma", "kernel": "gemm256q_kernel" if dtype != "fp32" else "gemm_nt_kernel<float>",
             "achieved": round(achieved, 1), "peak": PEAK[dtype], "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK[dtype], 4), "traffic": traffic,
+            "frac": round(achieved / PEAK[dtype], 4), "traffic": traffic, "algorithmic_bytes": round(alg_bytes),
+            "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
             "rows_per_launch": ws.R, "fused_ln": bool(ws.fused), "launches_per_slab": len(launches), "avg_launch_us": round(avg_ms * 1e3, 1),
             "flops_per_launch": flops / len(launches)}
 

@@ -15,7 +15,7 @@ timeout -k 10 400 python3 bench.py --dtype $DT > $OUT/bench_$DT.json 2> $OUT/ben
 cut -c1-600 $OUT/bench_$DT.json
 # kernel trace + stats of the same workload (sampling leg at 2 lanes, then the roofline launches)
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python3 bench.py --dtype $DT --steps 5 --warmup 2 --no-alt --no-train --no-cpu-baseline > $OUT/kt.log 2>&1
-# PMC passes over one eager step of two row slabs + the roofline launches (33 x 4 GEMM dispatches of a full slab)
+# PMC passes over one eager step of two row slabs + the roofline launches (45 x 4 GEMM dispatches of a full slab)
 B1="bench.py --dtype $DT --spots 262144 --no-graph --lanes 1 --steps 1 --warmup 0 --no-alt --no-train --no-cpu-baseline"
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- python3 $B1 > $OUT/fetch.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- python3 $B1 > $OUT/write.log 2>&1

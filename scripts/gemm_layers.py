@@ -16,13 +16,13 @@ for buf in (ws.xp, ws.s, ws.xn, ws.o, ws.u, ws.h, ws.gates if ws.fused else ws.m
 import time
 t0 = time.time()
 while time.time() - t0 < 2.0:          # a fresh box ramps its clocks for a second or two
-    for _, _, _, f in L: f()
+    for _, _, _, f, _ in L: f()
     torch.cuda.synchronize()
 names = ["in"] + (["gate", "ln1", "qkv", "proj", "ln2", "fc1", "fc2"] if ws.fused else ["ada", "qkv", "proj", "fc1", "fc2"]) * 6 + ["fada", "out"]
 tot = {}
 for rep in range(5):
     evs = []
-    for m, n, k, f in L:
+    for m, n, k, f, _ in L:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); f(); b.record(); evs.append((a, b))
     torch.cuda.synchronize()

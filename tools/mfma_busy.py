@@ -1,14 +1,14 @@
 """MFMA utilisation of the GEMM kernel from one rocprofv3 PMC pass (SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE) over
-`bench.py --no-graph --lanes 1 --steps 1 --warmup 0`: the LAST 99 gemm dispatches are the roofline launches.
+`bench.py --no-graph --lanes 1 --steps 1 --warmup 0`: the LAST 3 x 45 gemm dispatches (3 x 33 without the fused LayerNorm form) are the roofline launches.
     busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)
-usage: python tools/mfma_busy.py <mfma_dir> [n=99]"""
+usage: python tools/mfma_busy.py <mfma_dir> [n=135]"""
 import csv
 import glob
 import os
 import sys
 
 d = sys.argv[1]
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 99
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 135
 rows = []
 for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
     rows += [r for r in csv.DictReader(open(f)) if "gemm" in r["Kernel_Name"]]

@@ -1,12 +1,12 @@
 """Cross-check of bench.py's event-timed GEMM launch average against the rocprofv3 kernel trace of the same command.
-usage: python tools/roofline_check.py <kt_results.db | kt_kernel_trace.csv> [launches=33] [reps=3]
+usage: python tools/roofline_check.py <kt_results.db | kt_kernel_trace.csv> [launches=45] [reps=3]
 The roofline launches are the last reps*launches GEMM dispatches before the training leg starts (its first kernel is
 add_noise_splice); split-K reduces are not GEMM launches."""
 import sqlite3
 import sys
 
 db = sys.argv[1]
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 33
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 45
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 if db.endswith(".csv"):                      # rocprofv3 --output-format csv: *_kernel_trace.csv
     import csv
