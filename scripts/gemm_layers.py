@@ -26,7 +26,7 @@ for rep in range(5):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); f(); b.record(); evs.append((a, b))
     torch.cuda.synchronize()
-    for (m, n, k, f), (a, b), nm in zip(L, evs, names):
+    for (m, n, k, f, _), (a, b), nm in zip(L, evs, names):
         t = tot.setdefault(nm, [0.0, 0, 0.0]); t[0] += a.elapsed_time(b); t[1] += 1; t[2] = 2.0 * m * n * k
 s = fl_all = 0
 for nm, (ms, cnt, fl) in tot.items():

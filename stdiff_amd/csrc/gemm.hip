@@ -1138,6 +1138,12 @@ __global__ __launch_bounds__(512, 1) void gemm256q_kernel(Params p) {
             set_tile(next, m0, n0);
             prologue();
         }
+#ifdef STDIFF_GEMM_NOEPI      // timing experiment only: the tile's results are dropped (upper bound of any epilogue overlap)
+        _Pragma("unroll") for (int a0 = 0; a0 < 2; ++a0) _Pragma("unroll") for (int a1 = 0; a1 < 2; ++a1)
+        _Pragma("unroll") for (int a2 = 0; a2 < 4; ++a2) _Pragma("unroll") for (int a3 = 0; a3 < 2; ++a3)
+            asm volatile("" ::"v"(acc[a0][a1][a2][a3]));
+        if (p.M >= 0) {} else
+#endif
         if constexpr (MODE == 1) {
             epi_tile256_lnmod(p, acc, cla, tid, wid, lane, em0, en0, nq);
         } else if constexpr (MODE == 2) {
