@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define STDIFF_ABI_VERSION 7
+#define STDIFF_ABI_VERSION 8
 
 enum { STDIFF_F32 = 0, STDIFF_BF16 = 1 };
 
@@ -319,6 +319,65 @@ typedef struct {
 } stdiff_dit_workspace;
 int stdiff_dit_forward(const stdiff_dit_weights* w, const stdiff_dit_workspace* ws, const void* xp, const void* s,
                        float* eps, int ldeps, void* stream);
+
+/* ---------------------------------------------------------------- whole-denoiser training pass
+ * The forward of stDiff_train.py:72 (DiT_stDiff.forward, stDiff_model.py:231-243, on one mini-batch = one attention
+ * chunk) keeping what the backward needs, and the backward of :77 (loss.backward() through the denoiser), each as ONE
+ * enqueue of ~110 resp. ~190 launches.  All buffers are caller-owned.  16-bit activations have w->dtype; "fp32" ones
+ * are float.  Shapes: C = cells of the batch, H hidden, G genes, Gp = G rounded up to 64 (operand padding). */
+typedef struct {
+    const void* w;          /* packed operand [out, in_padded] of w->dtype (nn.Linear layout) */
+    const float* b;         /* bias fp32 [out] */
+    float* gw; float* gb;   /* gradients fp32 [out, in] (UNPADDED, contiguous) and [out]: written by stdiff_dit_backward */
+} stdiff_train_linear;
+typedef struct { stdiff_train_linear qkv, proj, fc1, fc2, ada; } stdiff_train_block;   /* [3H,H] [H,H] [4H,H] [H,4H] [6H,H] */
+typedef struct {
+    int dtype, G, Gp, H, heads, depth;
+    stdiff_train_linear t0, t2;                 /* time_emb.mlp.0 [H,256], time_emb.mlp.2 [H,H] */
+    stdiff_train_linear cond, in;               /* cond_layer.0, in_layer.0: [H,Gp] packed, gradients [H,G] */
+    stdiff_train_linear fada, out;              /* out_layer.adaLN_modulation.1 [2H,H], out_layer.linear [G,H] */
+    const stdiff_train_block* blocks;           /* host array [depth] */
+    const float* freqs;                         /* as for stdiff_timestep_embedding */
+} stdiff_train_weights;
+typedef struct {            /* saved by block k's forward */
+    float* h; float* hmid;                      /* fp32 [C,H]: block input, after the attention branch */
+    void* mod;                                  /* [C,6H] adaLN output */
+    void* xn1; void* xn2; void* qkv; void* o;   /* [C,H] [C,H] [C,3H] [C,H] */
+    float* lse;                                 /* fp32 [C,heads] */
+    void* pa; void* pm;                         /* [C,H] branch outputs before the gate (proj / fc2) */
+    void* upre; void* u;                        /* [C,4H] fc1 before / after GELU */
+    float* mean1; float* rstd1; float* mean2; float* rstd2;   /* fp32 [C] */
+} stdiff_train_block_acts;
+typedef struct {
+    int C;
+    const int32_t* cu_rows;                     /* device int32 {0, C} */
+    void* xp; void* yp;                         /* packed inputs [C,Gp]: x_noisy and x_cond */
+    void* e0; void* a1; void* e1;               /* [C,256] [C,H] [C,H]: time MLP */
+    float* temb; float* c; void* s;             /* fp32 [C,H], fp32 [C,H], [C,H] = silu(c) */
+    const stdiff_train_block_acts* blocks;      /* host array [depth] */
+    float* h_last;                              /* fp32 [C,H]: output of the last block */
+    void* fmod; void* xnf; float* meanf; float* rstdf;     /* [C,2H] [C,H] fp32 [C] fp32 [C] */
+    float* eps;                                 /* fp32 [C,G]: the forward's result */
+    /* backward: deps = d loss / d eps as the packed operand [C,Gp] (stdiff_masked_mse writes it); the rest is scratch */
+    void* deps; float* dh; void* dxn; void* dmod[2]; void* dfmod; void* dbr; void* du; void* dupre; void* do_; void* dqkv;
+    float* delta; float* ds32; float* dc; void* dcT; void* de1; void* da1; void* dhT;
+    /* [C,Gp] [C,H]f32 [C,H] 2x[C,6H] [C,2H] [C,H] [C,4H] [C,4H] [C,H] [C,3H] f32[C,heads] f32[C,H] f32[C,H] [C,H] x4 */
+    void* tr[2][2];        /* G % 8 != 0 only: [stream: main, side][dY^T, X^T] transposed copies [max(Gp,H), round_up(C,64)] */
+    void* splitk_ws; long long splitk_bytes;             /* split-K scratch of the launches on `stream` (may be NULL) */
+    void* splitk_ws_side; long long splitk_side_bytes;   /* ... of the launches on the side stream */
+} stdiff_train_acts;
+/* side_stream (NULL = none): the adaLN projections of the forward and the weight-gradient jobs of the backward are
+ * issued there and joined with events the library creates once per device (hipEventDisableTiming; no device memory):
+ * under stream capture they become parallel branches of the graph.  Results do not depend on it. */
+int stdiff_dit_train_forward(const stdiff_train_weights* w, const stdiff_train_acts* a, const int64_t* t,
+                             void* side_stream, void* stream);
+/* after_bucket (may be NULL) is called ON THE HOST, in order, with i = 0 (final layer), 1 .. depth (blocks depth-1 .. 0),
+ * depth+1 (embedding layers) once everything that finishes that range of gradients has been enqueued on `stream`
+ * (side-stream jobs joined): the data-parallel step issues the range's all-reduce from it (stDiff_train.py has no
+ * counterpart; torch DDP's bucket hooks do the same). */
+typedef void (*stdiff_bucket_fn)(int bucket, void* user);
+int stdiff_dit_backward(const stdiff_train_weights* w, const stdiff_train_acts* a, void* side_stream,
+                        stdiff_bucket_fn after_bucket, void* user, void* stream);
 
 /* ---------------------------------------------------------------- hipGraph capture of a reverse step
  * begin/end bracket any sequence of the calls above on `stream`; launch replays it (model/sample.py:67-95 loop body

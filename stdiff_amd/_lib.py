@@ -58,6 +58,40 @@ class DitWorkspace(C.Structure):
                 ("ln_parts", vp), ("gates", vp)]
 
 
+class TrainLinear(C.Structure):
+    _fields_ = [("w", vp), ("b", vp), ("gw", vp), ("gb", vp)]
+
+
+class TrainBlock(C.Structure):
+    _fields_ = [(n, TrainLinear) for n in ("qkv", "proj", "fc1", "fc2", "ada")]
+
+
+class TrainWeights(C.Structure):
+    _fields_ = [("dtype", i32), ("G", i32), ("Gp", i32), ("H", i32), ("heads", i32), ("depth", i32)] + \
+               [(n, TrainLinear) for n in ("t0", "t2", "cond", "in_", "fada", "out")] + \
+               [("blocks", C.POINTER(TrainBlock)), ("freqs", vp)]
+
+
+class TrainBlockActs(C.Structure):
+    _fields_ = [(n, vp) for n in ("h", "hmid", "mod", "xn1", "xn2", "qkv", "o", "lse", "pa", "pm", "upre", "u",
+                                  "mean1", "rstd1", "mean2", "rstd2")]
+
+
+class TrainActs(C.Structure):
+    _fields_ = [("C", i32), ("cu_rows", vp)] + \
+               [(n, vp) for n in ("xp", "yp", "e0", "a1", "e1", "temb", "c", "s")] + \
+               [("blocks", C.POINTER(TrainBlockActs))] + \
+               [(n, vp) for n in ("h_last", "fmod", "xnf", "meanf", "rstdf", "eps", "deps", "dh", "dxn")] + \
+               [("dmod", vp * 2)] + \
+               [(n, vp) for n in ("dfmod", "dbr", "du", "dupre", "do_", "dqkv", "delta", "ds32", "dc", "dcT", "de1",
+                                  "da1", "dhT")] + \
+               [("tr", (vp * 2) * 2), ("splitk_ws", vp), ("splitk_bytes", C.c_longlong),
+                ("splitk_ws_side", vp), ("splitk_side_bytes", C.c_longlong)]
+
+
+BucketFn = C.CFUNCTYPE(None, i32, vp)
+
+
 class AdamWArgs(C.Structure):
     _fields_ = [("params", vp), ("grads", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("n", i64),
                 ("sumsq", vp), ("step_dev", vp), ("scal", vp),
@@ -98,6 +132,8 @@ _SIGS = {
     "stdiff_grad_sumsq": (i32, [vp, i64, vp, vp]),
     "stdiff_clip_adamw": (i32, [C.POINTER(AdamWArgs), vp]),
     "stdiff_dit_forward": (i32, [C.POINTER(DitWeights), C.POINTER(DitWorkspace), vp, vp, vp, i32, vp]),
+    "stdiff_dit_train_forward": (i32, [C.POINTER(TrainWeights), C.POINTER(TrainActs), vp, vp, vp]),
+    "stdiff_dit_backward": (i32, [C.POINTER(TrainWeights), C.POINTER(TrainActs), vp, BucketFn, vp, vp]),
     "stdiff_graph_begin": (i32, [vp]),
     "stdiff_graph_end": (i32, [vp, C.POINTER(vp)]),
     "stdiff_graph_launch": (i32, [vp, vp]),
@@ -126,7 +162,7 @@ def lib(fp16=False):
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.stdiff_abi_version() != 7:
+        if L.stdiff_abi_version() != 8:
             raise RuntimeError(f"{base} ABI version mismatch")
         if L.stdiff_h16_format() != int(bool(fp16)):
             raise RuntimeError(f"{base} was built with the wrong 16-bit operand format")

@@ -94,6 +94,10 @@ class TrainCore:
         self.side_mode = int(os.environ.get("STDIFF_TRAIN_SIDE_STREAM", "1"))
         self.ws_splitk_side = None
         self._side, self._side_prev, self._side_on = None, None, False
+        # Forward and backward are ONE C-ABI enqueue each (stdiff_dit_train_forward / stdiff_dit_backward);
+        # STDIFF_TRAIN_ENQUEUE=py issues the same launches one by one from Python (second implementation, tests)
+        self.c_enqueue = os.environ.get("STDIFF_TRAIN_ENQUEUE", "c") != "py"
+        self._cw = None
 
     def refresh_weights(self, pack=True):
         """fp32 master weights -> packed MFMA operands (the backward reads the same [out, in] copies K-major)."""
@@ -163,9 +167,72 @@ class TrainCore:
     def _lin(self, name):
         return self.pw.w[name + ".weight"], self.pw.b(name + ".bias")
 
+    # ------------------------------------------------------------------ the C-ABI view of weights / activations
+    def _c_weights(self):
+        """stdiff_train_weights over the packed operands, the biases and the flat gradient buffer (addresses are
+        stable: the optimizer and refresh() write in place)."""
+        if self._cw is not None:
+            return self._cw[0]
+        p = L.ptr
+
+        def lin(name):
+            return L.TrainLinear(p(self.pw.w[name + ".weight"]), p(self.pw.b(name + ".bias")),
+                                 p(self.g[name + ".weight"]), p(self.g[name + ".bias"]))
+        blocks = (L.TrainBlock * max(1, self.depth))()
+        for k in range(self.depth):
+            b = f"blks.{k}."
+            blocks[k] = L.TrainBlock(lin(b + "attn.qkv"), lin(b + "attn.proj"), lin(b + "mlp.fc1"), lin(b + "mlp.fc2"),
+                                     lin(b + "adaLN_modulation.1"))
+        w = L.TrainWeights()
+        w.dtype, w.G, w.Gp, w.H, w.heads, w.depth = L.dt_of(self.pw.w["in_layer.0.weight"]), self.G, self.Gp, self.H, \
+            self.heads, self.depth
+        w.t0, w.t2 = lin("time_emb.mlp.0"), lin("time_emb.mlp.2")
+        w.cond, w.in_ = lin("cond_layer.0"), lin("in_layer.0")
+        w.fada, w.out = lin("out_layer.adaLN_modulation.1"), lin("out_layer.linear")
+        w.blocks, w.freqs = blocks, p(self.pw.freqs)
+        self._cw = (w, blocks)
+        return w
+
+    def _c_acts(self, a):
+        """stdiff_train_acts over the buffer set `a` (cached in it; the side scratch is filled in when a side stream
+        first exists)."""
+        ca = a.get("_c")
+        if ca is None:
+            p, D = L.ptr, self.depth
+            blocks = (L.TrainBlockActs * max(1, D))()
+            for k in range(D):
+                blocks[k] = L.TrainBlockActs(*[p(a[n][k]) for n in ("h", "hmid", "mod", "xn1", "xn2", "qkv", "o", "lse", "pa",
+                                                                    "pm", "upre", "u", "mean1", "rstd1", "mean2", "rstd2")])
+            ca = L.TrainActs()
+            ca.C, ca.cu_rows, ca.blocks, ca.h_last = a["C"], p(a["cu"]), blocks, p(a["h"][D])
+            for n in ("xp", "yp", "e0", "a1", "e1", "temb", "c", "s", "fmod", "xnf", "meanf", "rstdf", "eps", "deps", "dh",
+                      "dxn", "dfmod", "dbr", "du", "dupre", "dqkv", "delta", "ds32", "dc", "de1", "da1"):
+                setattr(ca, n, p(a[n]))
+            ca.do_, ca.dcT, ca.dhT = p(a["do"]), p(a["dcT_"]), p(a["dhT_"])
+            ca.dmod[0], ca.dmod[1] = p(a["dmod"][0]), p(a["dmod"][1])
+            if "tr" in a:
+                for i in range(2):
+                    ca.tr[i][0], ca.tr[i][1] = p(a["tr"][i][0]), p(a["tr"][i][1])
+            ca.splitk_ws, ca.splitk_bytes = p(self.ws_splitk), self.ws_splitk.numel() * 4
+            a["_c"] = ca = (ca, blocks)
+        ca = ca[0]
+        if self.ws_splitk_side is not None and not ca.splitk_ws_side:
+            ca.splitk_ws_side, ca.splitk_side_bytes = L.ptr(self.ws_splitk_side), self.ws_splitk_side.numel() * 4
+        return ca
+
+    def _c_side(self):
+        """The side stream's handle when this pass forks (same rule as the Python enqueue), else None."""
+        self._side_begin()
+        on, self._side_on = self._side_on, False
+        return self._side.cuda_stream if on else None
+
     # ------------------------------------------------------------------ forward (stDiff_model.py:231-243)
     def forward(self, a, t):
         """a['xp'], a['yp'] hold the packed inputs; returns eps fp32 [C, G] (a['eps'])."""
+        if self.c_enqueue:
+            side = self._c_side()
+            L.check(L.lib().stdiff_dit_train_forward(self._c_weights(), self._c_acts(a), L.ptr(t), side, L.stream()))
+            return a["eps"]
         H, D = self.H, self.depth
         g = self._gemm
         ops.timestep_embedding(t, self.pw.freqs, out=a["e0"])
@@ -276,6 +343,20 @@ class TrainCore:
         """a['deps'] holds d loss / d eps as the packed operand [C, Gp]; fills self.flat_g (overwrite).
         after_bucket(i) is called when the i-th range of bucket_ranges() is final (DDP overlap)."""
         H, D = self.H, self.depth
+        if self.c_enqueue:
+            side = self._c_side()
+            err = []
+
+            def hook(i, _user):               # an exception must not unwind through the C frames
+                try:
+                    after_bucket(i)
+                except BaseException as e:    # noqa: BLE001
+                    err.append(e)
+            cb = L.BucketFn(hook) if after_bucket else L.C.cast(None, L.BucketFn)
+            L.check(L.lib().stdiff_dit_backward(self._c_weights(), self._c_acts(a), side, cb, None, L.stream()))
+            if err:
+                raise err[0]
+            return
         deps = a["deps"]
         self._side_begin()
         # ---- final layer

@@ -165,6 +165,59 @@ def test_train_steps_golden_fp32(golden_dir, use_graph, side, monkeypatch):
     assert torch.equal(sd["condi_emb.weight"].cpu(), p0["condi_emb.weight"])
 
 
+@pytest.mark.parametrize("dtype,G,side", [("fp32", 64, "1"), ("bf16", 64, "2"), ("fp32", 50, "2"), ("bf16", 200, "1")])
+def test_c_enqueue_equals_python_enqueue(dtype, G, side, monkeypatch):
+    """stdiff_dit_train_forward / stdiff_dit_backward (ONE C-ABI enqueue each, the default) against the same launches
+    issued one by one from Python (STDIFF_TRAIN_ENQUEUE=py): eps, loss, every gradient and the weights after two
+    iterations agree bit for bit (up to the run-to-run variation of the atomically summed gradient norm where it
+    enters the clip factor), without and with the weight-gradient fork (side = "2": eager fork), for a gene count
+    that takes the transposed-copy path (50) and in both compute types; the bucket callback fires depth + 2 times in
+    order."""
+    from stdiff_amd.train_engine import TrainEngine
+    monkeypatch.setenv("STDIFF_TRAIN_SIDE_STREAM", side)
+    H, depth, heads, T, C = 128, 3, 4, 1000, 72
+    mask = O.kfold_mask(G, 1)
+    st = (O.synth_expression(2 * C, G, 5) * 2 - 1).astype(np.float32)
+    gen = torch.Generator().manual_seed(3)
+    res = {}
+    for mode in ("c", "py"):
+        m, _ = build(G, H, depth, heads, 70, dtype)
+        te = TrainEngine(m, lr=1e-3, diffusion_step=T, mask=mask)
+        assert te.c_enqueue
+        te.c_enqueue = mode == "c"
+        gen.manual_seed(3)
+        out = []
+        for i in range(2):
+            x = torch.from_numpy(st[i * C:(i + 1) * C]).to(DEV)
+            xc = (x * torch.from_numpy(mask).to(DEV)).float()
+            noise = torch.randn(C, G, generator=gen).to(DEV)
+            tt = torch.randint(1, T, (C,), generator=gen).to(DEV)
+            loss, gn = te.step(x, xc, noise=noise, timesteps=tt)
+            out.append((float(loss), float(gn), te.acts(C)["eps"].clone(), te.flat_g.clone()))
+        out.append(te.flat_p.clone())
+        if mode == "c":                      # bucket order of the C backward (what the data-parallel step hooks into)
+            seen = []
+            a = te.acts(C)
+            te.backward(a)                   # on the updated weights: the reference point for the hooked call
+            plain = te.flat_g.clone()
+            te.backward(a, after_bucket=seen.append)
+            assert seen == list(range(depth + 2))
+            assert torch.equal(te.flat_g, plain)            # same inputs -> same gradients, bucket hooks or not
+        res[mode] = out
+    for i in range(2):
+        # loss and gradient norm are summed with float atomics (their last bits vary run to run); tensors are exact
+        for j in (0, 1):
+            assert abs(res["c"][i][j] - res["py"][i][j]) < 1e-5 * res["py"][i][j], (i, j)
+        if i == 0 or max(res["py"][0][1], res["c"][0][1]) < 1.0:
+            # bit for bit -- the second iteration too unless the first one clipped (the clip factor carries the norm's
+            # varying last bits into the weights)
+            assert torch.equal(res["c"][i][2], res["py"][i][2]) and torch.equal(res["c"][i][3], res["py"][i][3]), i
+        else:
+            tol = 1e-5 if dtype == "fp32" else 1e-2
+            assert relerr(res["c"][i][2], res["py"][i][2]) < tol and relerr(res["c"][i][3], res["py"][i][3]) < tol, i
+    assert relerr(res["c"][2], res["py"][2]) < 1e-6
+
+
 @pytest.mark.parametrize("G", [33, 50])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_train_odd_gene_counts_against_oracle(G, use_graph):
