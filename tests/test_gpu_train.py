@@ -215,7 +215,10 @@ def test_c_enqueue_equals_python_enqueue(dtype, G, side, monkeypatch):
         else:
             tol = 1e-5 if dtype == "fp32" else 1e-2
             assert relerr(res["c"][i][2], res["py"][i][2]) < tol and relerr(res["c"][i][3], res["py"][i][3]) < tol, i
-    assert relerr(res["c"][2], res["py"][2]) < 1e-6
+    if max(res["py"][0][1], res["c"][0][1], res["py"][1][1], res["c"][1][1]) < 1.0:
+        assert torch.equal(res["c"][2], res["py"][2])
+    else:                                            # Adam's normalisation amplifies the clip factor's last bits
+        assert relerr(res["c"][2], res["py"][2]) < 1e-4
 
 
 @pytest.mark.parametrize("G", [33, 50])
