@@ -196,8 +196,9 @@ __global__ __launch_bounds__(256, ATTN_FWD_OCC) void attn_fwd_kernel(const T* __
                                                        const int32_t* __restrict__ cu_rows, int heads, float c_log2) {
     using C = ACfg<T, D>;
     constexpr bool BF = sizeof(T) == 2;
-    __shared__ __attribute__((aligned(16))) unsigned char kls[BKV * C::RSTR];
-    __shared__ __attribute__((aligned(16))) unsigned char vls[BKV * C::TSTR];
+    // two tile buffers: tile j + 1 is stored while slower waves still read tile j, one barrier per tile
+    __shared__ __attribute__((aligned(16))) unsigned char kls2[2][BKV * C::RSTR];
+    __shared__ __attribute__((aligned(16))) unsigned char vls2[2][BKV * C::TSTR];
 
     // XCD-aware order: workgroups go to the 8 XCDs round-robin in linear order, so with the natural (query tile
     // fastest) order the query tiles of one (chunk, head) -- which all read the same K and V rows -- land on
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(256, ATTN_FWD_OCC) void attn_fwd_kernel(const T* __
     if constexpr (BF) { sk.gload(kbase, ldqkv, r0, 0, len, tid); sv.gload(vbase, ldqkv, r0, 0, len, tid); }
     for (int j = 0; j < ntiles; ++j) {
         const int k0 = j * BKV;
-        __syncthreads();
+        unsigned char* kls = kls2[j & 1];
+        unsigned char* vls = vls2[j & 1];
         if constexpr (!BF) { sk.gload(kbase, ldqkv, r0, k0, len, tid); sv.gload(vbase, ldqkv, r0, k0, len, tid); }
         sk.sstore(kls, nullptr, tid);
         if constexpr (BF) sv.sstore(nullptr, vls, tid); else sv.sstore(vls, nullptr, tid);
@@ -252,7 +254,6 @@ __global__ __launch_bounds__(256, ATTN_FWD_OCC) void attn_fwd_kernel(const T* __
         // rescale multiplies by exactly 1, so nothing changes but the work: the accumulators stay in place instead of
         // a read-modify-write of all of them per tile).  exp2 is the bare v_exp_f32.
         constexpr float LAZY = 6.0f;
-        const bool two = k0 + 32 < len;
         constexpr bool PREV = BF && D <= 64;                         // registers allow it (d = 128: 226 VGPRs already)
         bf16x8 vf[2][PREV ? D / 32 : 1][2];
         if constexpr (PREV) {
@@ -260,13 +261,10 @@ __global__ __launch_bounds__(256, ATTN_FWD_OCC) void attn_fwd_kernel(const T* __
             tr_fragments<D>(vf[1], vls, 1, lane);                    // a tile past the chunk: finite stale data x P = 0
             __builtin_amdgcn_sched_barrier(0);
         }
-        f32x16 sa = rows_dot_regs<T, D>(kls, 0, qf, lane);           // S^T[key, q], raw scores
-        f32x16 sb;
-        if (two) sb = rows_dot_regs<T, D>(kls, 1, qf, lane);
-        else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sb[r] = -INFINITY;
-        }
+        // S^T[key, q], raw scores.  Both 32-key halves always: the staged rows past the chunk are copies of its last
+        // row (finite), the mask below turns their scores into -inf, so P = 0 there and the V MFMAs add exact zeros
+        f32x16 sa = rows_dot_regs<T, D>(kls, 0, qf, lane);
+        f32x16 sb = rows_dot_regs<T, D>(kls, 1, qf, lane);
         if (k0 + 64 > len) {                                         // keys past the chunk get -inf
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -298,10 +296,10 @@ __global__ __launch_bounds__(256, ATTN_FWD_OCC) void attn_fwd_kernel(const T* __
         l_run += ps;
         if constexpr (PREV) {
             tr_mma<D>(o, vf[0], sa);                                 // O^T[d, q] += V^T . P^T
-            if (two) tr_mma<D>(o, vf[1], sb);
+            tr_mma<D>(o, vf[1], sb);
         } else {
             tr_accumulate<T, D>(o, vls, 0, sa, lane);
-            if (two) tr_accumulate<T, D>(o, vls, 1, sb, lane);
+            tr_accumulate<T, D>(o, vls, 1, sb, lane);
         }
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
