@@ -492,10 +492,12 @@ __device__ __forceinline__ f32x4 lds_read16(unsigned addr) {
 
 // Whole-tile epilogue of the two-phase kernel for out = res + gate * (acc + bias) (attn.proj / mlp.fc2: the fp32
 // residual stream).  Same quarter images as epi_quarter256, but the side inputs (gate: 8 B, res: 16 B per lane and
-// row) of batch b + 1 are requested BEFORE batch b is read from the image, converted and stored: their HBM latency
-// (8 batches per tile, ~1.5 us each when exposed) runs under the previous batch and under the put + barrier of the
-// next quarter.  Fully unrolled so that the two register sets are static.
-template <bool CBF, bool STATS = false>
+// row) of batch b + 2 are requested BEFORE batch b is read from the image, converted and stored: their HBM latency
+// (8 batches per tile, ~1.5 us each when exposed) runs under the two previous batches and under the put + barrier of
+// the next quarter (SLOTS = 3: two batches = 96 KiB per CU in flight; SLOTS = 2: one).  Measured at a 131 072-row slab:
+// fc2 968 -> 955 us, proj unchanged (its 2.4 GB per launch already move at 5.4 TB/s: HBM-bound as a whole).  Fully
+// unrolled so that the register sets are static.
+template <bool CBF, bool STATS = false, int SLOTS = 2>
 __device__ __forceinline__ void epi_tile256_gate_res(const Params& p, const f32x4 (&acc)[2][2][4][2], unsigned cla,
                                                      int wid, int lane, int m0, int n0, int nq) {
     asm volatile("" : "+v"(lane));       // per-lane offsets are recomputed per tile, not kept live across the K loop
@@ -505,8 +507,8 @@ __device__ __forceinline__ void epi_tile256_gate_res(const Params& p, const f32x
     const int gnc = min(gn, p.N - 4);
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) bias4 = *(const f32x4*)(p.bias + gnc);
-    u32x2 graw[2][4];
-    f32x4 r[2][4];
+    u32x2 graw[SLOTS][4];            // SLOTS - 1 batches ahead (3 where the kernel's register budget allows it)
+    f32x4 r[SLOTS][4];
     auto row_of = [&](int b, int ps) {                   // batch b = 2 * quarter + pb
         const int q = b >> 1, i = wid + 8 * ((b & 1) * 4 + ps);
         return m0 + (q >> 1) * 128 + (q & 1) * 32 + (i >> 5) * 64 + ((i >> 4) & 1) * 16 + (i & 15);
@@ -520,6 +522,7 @@ __device__ __forceinline__ void epi_tile256_gate_res(const Params& p, const f32x
         }
     };
     issue(0, 0);
+    if constexpr (SLOTS > 2) issue(1, 1);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (q >= nq) break;                              // half unit: two quarters
@@ -539,8 +542,8 @@ __device__ __forceinline__ void epi_tile256_gate_res(const Params& p, const f32x
         STDIFF_BARRIER();
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {
-            const int b = 2 * q + pb, slot = b & 1;
-            if (b + 1 < 8) issue(b + 1, slot ^ 1);
+            const int b = 2 * q + pb, slot = b % SLOTS;
+            if (b + SLOTS - 1 < 8) issue(b + SLOTS - 1, (b + SLOTS - 1) % SLOTS);
             f32x4 v[4];
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
@@ -1147,7 +1150,7 @@ __global__ __launch_bounds__(512, 1) void gemm256q_kernel(Params p) {
         if constexpr (MODE == 1) {
             epi_tile256_lnmod(p, acc, cla, tid, wid, lane, em0, en0, nq);
         } else if constexpr (MODE == 2) {
-            epi_tile256_gate_res<false, true>(p, acc, cla, wid, lane, em0, en0, nq);
+            epi_tile256_gate_res<false, true, 3>(p, acc, cla, wid, lane, em0, en0, nq);
         } else if (p.vec == 2 && p.c_bf16 && !p.C2 && p.epi <= STDIFF_EPI_GELU) {     // bias / SiLU / GELU, 16-byte C rows
             unsigned char* img = smem + 5 * HALF;
             if (p.epi == STDIFF_EPI_GELU) epi_tile256_bf16<STDIFF_EPI_GELU>(p, acc, img, tid, wid, lane, em0, en0, nq);
