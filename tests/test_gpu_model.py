@@ -450,17 +450,18 @@ def test_errors_and_quirks():
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("H", [128, 256])
-def test_fused_ln_forward_against_unfused(dtype, H, monkeypatch):
+@pytest.mark.parametrize("H,heads", [(128, 4), (256, 4), (384, 6), (512, 8), (2048, 16)])
+def test_fused_ln_forward_against_unfused(dtype, H, heads, monkeypatch):
     """The fused-LN form of the denoiser forward (LayerNorm + modulate as the epilogue of the adaLN GEMM, no [R, 6H]
-    modulation matrix) against the plain form (STDIFF_FUSED_LN=0).  H = 128: every LayerNorm's statistics come from the
-    statistics pass, and eps is bit-identical.  H = 256: the gated-residual epilogues hand over partial row moments
-    (another, equally exact summation order), and eps agrees to the rounding of one 16-bit operand.  In both cases a
-    chunk run alone equals the chunk inside a larger run bit for bit (every workspace of a model takes the same form)."""
+    modulation matrix) against the plain form (STDIFF_FUSED_LN=0).  H = 128, 384: every LayerNorm's statistics come from
+    the statistics pass, and eps is bit-identical.  H = 256, 512, 2048 (1, 2, 8 parts per row; head dims 64, 64, 128): the
+    gated-residual epilogues hand over partial row moments (another, equally exact summation order), and eps agrees to
+    the rounding of one 16-bit operand.  In every case a chunk run alone equals the chunk inside a larger run bit for bit
+    (every workspace of a model takes the same form), and the first chunk matches the oracle."""
     from stdiff_amd import engine as E
     from stdiff_amd.model.stDiff_model import DiT_stDiff
     from stdiff_amd.model.stDiff_scheduler import NoiseScheduler
-    G, depth, heads = 72, 2, 4
+    G, depth = 72, 2
     lens = [512] * 4 + [512, 300, 45]                      # 2905 rows, ragged
     R = sum(lens)
     p = O.make_params(G, H, depth, 77)
