@@ -661,6 +661,16 @@ __device__ __forceinline__ void epi_tile256_bf16(const Params& p, const f32x4 (&
 // r < 256 combines row r's partial moments ONCE per tile into (mean, rstd) in LDS (2 KiB behind the image) while they
 // fly, and the second half's residual loads are issued before the first half is converted.  LDS accesses are asm for
 // the same reason as in epi_tile256_gate_res.
+#ifdef STDIFF_GEMM_STAMPS
+__device__ unsigned long long g_stamps[256 * 8 * 8];      // [block][tile][0..3 realtime (100 MHz), 4..7 shader clock]
+#define STDIFF_STAMP(k) do { if (tid == 0 && blockIdx.x < 256 && iter < 8) { g_stamps[(blockIdx.x * 8 + iter) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); g_stamps[(blockIdx.x * 8 + iter) * 8 + 4 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+// sub-stamps of the LN_MOD epilogue go to the shader-clock slots (realtime): 4 statistics ready, 5 first half staged,
+// 6 first half stored, 7 second half staged
+#define STDIFF_SUBSTAMP(k) do { if (tid == 0 && blockIdx.x < 256 && dbg_iter < 8) g_stamps[(blockIdx.x * 8 + dbg_iter) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STDIFF_SUBSTAMP(k) do {} while (0)
+#define STDIFF_STAMP(k) do {} while (0)
+#endif
 __device__ __forceinline__ void lds_write8(unsigned addr, u32x2 v) {
     asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
@@ -670,7 +680,7 @@ __device__ __forceinline__ u32x2 lds_read8(unsigned addr) {
     return v;
 }
 __device__ __forceinline__ void epi_tile256_lnmod(const Params& p, const f32x4 (&acc)[2][2][4][2], unsigned imga,
-                                                  int tid, int wid, int lane, int m0, int n0, int nq) {
+                                                  int tid, int wid, int lane, int m0, int n0, int nq, int dbg_iter = 0) {
     asm volatile("" : "+v"(lane), "+v"(tid));   // per-lane offsets are recomputed per tile, not kept live across the K loop
     const int wr = wid >> 2, wc = wid & 3, fr = lane & 15, fq = lane >> 4;
     const int c0 = n0 >> 1;                      // first output column of this tile
@@ -725,6 +735,7 @@ __device__ __forceinline__ void epi_tile256_lnmod(const Params& p, const f32x4 (
     }
     STDIFF_LGKMCNT0();
     STDIFF_BARRIER();
+    STDIFF_SUBSTAMP(4);
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh) {
         if (2 * mh >= nq) break;                         // half unit: rows of acc[0] only
@@ -754,6 +765,7 @@ __device__ __forceinline__ void epi_tile256_lnmod(const Params& p, const f32x4 (
         }
         STDIFF_LGKMCNT0();
         STDIFF_BARRIER();
+        if (mh) STDIFF_SUBSTAMP(6);
         const int pair = tid & 15, gn = c0 + pair * 8;
         f32x4 v[4];
 #pragma unroll
@@ -767,6 +779,7 @@ __device__ __forceinline__ void epi_tile256_lnmod(const Params& p, const f32x4 (
             const int gm = m0 + mh * 128 + (tid >> 4) + 32 * k;
             if (gm < p.M) __builtin_nontemporal_store(v[k], (f32x4*)((bf16_t*)p.C + (size_t)gm * p.ldc + gn));
         }
+        if (!mh) STDIFF_SUBSTAMP(5);
     }
 }
 
@@ -776,12 +789,6 @@ __device__ __forceinline__ void epi_tile256_lnmod(const Params& p, const f32x4 (
 // LDS-DMA BEFORE the epilogue and lands while the block converts and stores its C tile: block launch, prologue
 // latency and most of the store drain disappear from the per-tile cost.  The epilogue uses raw barriers + lgkmcnt
 // waits (a __syncthreads would wait for the DMA and the global stores as well).
-#ifdef STDIFF_GEMM_STAMPS
-__device__ unsigned long long g_stamps[256 * 8 * 8];      // [block][tile][0..3 realtime (100 MHz), 4..7 shader clock]
-#define STDIFF_STAMP(k) do { if (tid == 0 && blockIdx.x < 256 && iter < 8) { g_stamps[(blockIdx.x * 8 + iter) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); g_stamps[(blockIdx.x * 8 + iter) * 8 + 4 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
-#else
-#define STDIFF_STAMP(k) do {} while (0)
-#endif
 __global__ __launch_bounds__(512, 1) void gemm256p_kernel(Params p) {
     constexpr int ROWB = 128, HALF = 128 * ROWB;          // one half-tile = 128 rows x 64 bf16 = 16 KiB
     __shared__ __attribute__((aligned(16))) unsigned char smem[9 * HALF];
@@ -1148,7 +1155,7 @@ __global__ __launch_bounds__(512, 1) void gemm256q_kernel(Params p) {
         if (p.M >= 0) {} else
 #endif
         if constexpr (MODE == 1) {
-            epi_tile256_lnmod(p, acc, cla, tid, wid, lane, em0, en0, nq);
+            epi_tile256_lnmod(p, acc, cla, tid, wid, lane, em0, en0, nq, iter);
         } else if constexpr (MODE == 2) {
             epi_tile256_gate_res<false, true, 3>(p, acc, cla, wid, lane, em0, en0, nq);
         } else if (p.vec == 2 && p.c_bf16 && !p.C2 && p.epi <= STDIFF_EPI_GELU) {     // bias / SiLU / GELU, 16-byte C rows
