@@ -1376,7 +1376,9 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
         int S = (int)fmin(fmin((double)smax, nk / 4.0), (double)sblocks / tiles);
         const long long per = (long long)a->M * ldws * 4;
         if (S > 1 && per * S > workspace_bytes) S = (int)(workspace_bytes / per);
-        if (S > 1) {
+        // a 2-way split does not pay for its reduce launch (3.39 -> 3.35 ms per 512-cell step with 3 as the minimum)
+        static const int smin = [] { const char* e = getenv("STDIFF_SPLITK_MIN"); return e && atoi(e) > 1 ? atoi(e) : 3; }();
+        if (S >= smin) {
             p.nk_per = cdiv(nk, S);
             p.ksplit = cdiv(nk, p.nk_per);
             p.ws = (float*)workspace; p.ldws = ldws;
