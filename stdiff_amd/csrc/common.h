@@ -134,6 +134,12 @@ __device__ __forceinline__ float ln_mod_apply(float v, float mean, float rstd, f
     return __builtin_fmaf(t, 1.0f + scale, shift);
 }
 
+// the same with (1 + scale) formed beforehand (the GEMM epilogue prepares it while its loads are in flight): same bits
+__device__ __forceinline__ float ln_mod_apply_pre(float v, float mean, float rstd, float one_plus_scale, float shift) {
+    const float t = (v - mean) * rstd;
+    return __builtin_fmaf(t, one_plus_scale, shift);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

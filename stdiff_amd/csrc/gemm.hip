@@ -733,6 +733,22 @@ __device__ __forceinline__ void epi_tile256_lnmod(const Params& p, const f32x4 (
         bsh[nt] = p.bias ? *(const f32x4*)(p.bias + gn) : f32x4{0.f, 0.f, 0.f, 0.f};
         bsc[nt] = p.bias ? *(const f32x4*)(p.bias + gn + 128) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // shift and 1 + scale, rounded through the 16-bit format, for both halves: arithmetic that needs neither the
+    // residual rows nor the statistics runs while those loads are in flight
+    f32x4 shv[2][4][2], opv[2][4][2];
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const f32x4 sh = acc[mh][0][mt][nt] + bsh[nt], sc = acc[mh][1][mt][nt] + bsc[nt];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    shv[mh][mt][nt][j] = bf2f(f2bf(sh[j]));
+                    opv[mh][mt][nt][j] = 1.0f + bf2f(f2bf(sc[j]));
+                }
+            }
     STDIFF_LGKMCNT0();
     STDIFF_BARRIER();
     STDIFF_SUBSTAMP(4);
@@ -751,11 +767,10 @@ __device__ __forceinline__ void epi_tile256_lnmod(const Params& p, const f32x4 (
             const float mean = __uint_as_float(st[mt][0]), rstd = __uint_as_float(st[mt][1]);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const f32x4 sh = acc[mh][0][mt][nt] + bsh[nt], sc = acc[mh][1][mt][nt] + bsc[nt];
                 const f32x4 xv = x[mh][mt][nt];
                 f32x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = ln_mod_apply(xv[j], mean, rstd, bf2f(f2bf(sc[j])), bf2f(f2bf(sh[j])));
+                for (int j = 0; j < 4; ++j) o[j] = ln_mod_apply_pre(xv[j], mean, rstd, opv[mh][mt][nt][j], shv[mh][mt][nt][j]);
                 u32x2 rr;
                 rr[0] = pack2bf(o[0], o[1]);
                 rr[1] = pack2bf(o[2], o[3]);
