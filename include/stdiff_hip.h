@@ -94,7 +94,7 @@ typedef struct {
     /* Row statistics of a residual stream [M, Hn] as partial moments, fp32 [M][parts][2] = (mean_p, M2_p) of `parts`
      * equal column ranges (M2 = sum of squared deviations from mean_p); mean = avg(mean_p), biased variance =
      * (sum M2_p + cols_per_part * sum (mean_p - mean)^2) / Hn.
-     *   ln_parts / ln_nparts: read by STDIFF_EPI_LN_MOD for its `res` (Hn = N/2).
+     *   ln_parts / ln_nparts: read by STDIFF_EPI_LN_MOD for its `res` (Hn = N/2); 1 <= ln_nparts <= 8, Hn % ln_nparts == 0.
      *   stats_out: if non-NULL (fp32 C, N % 256 == 0, 16-bit operands) this GEMM also WRITES the partial moments of the
      *   rows of C it produces, one part per 256-column tile ([M][N/256][2]): the epilogue that adds the gated branch
      *   to the residual stream hands the next LayerNorm its statistics, and no pass over C is needed for them. */
