@@ -74,9 +74,9 @@ extern "C" int stdiff_dit_forward(const stdiff_dit_weights* w, const stdiff_dit_
     if (!fused) STDIFF_CHECK_ARG(ws->mod && ws->fmod);
     if (fused) {
         // ---- fused-LN form (include/stdiff_hip.h, STDIFF_EPI_LN_MOD).  With H a multiple of 256 the gated-residual
-        // epilogues of proj / fc2 also hand the next LayerNorm its statistics (P parts per row); otherwise, and for
+        // epilogues of proj / fc2 also hand the next LayerNorm its statistics (P <= 8 parts per row); otherwise, and for
         // the first LayerNorm (after in_layer), a statistics pass reads h once.
-        const int P = H % 256 == 0 ? H / 256 : 0;
+        const int P = (H % 256 == 0 && H / 256 <= 8) ? H / 256 : 0;      // the LN_MOD epilogue combines up to 8 parts
         float* so = P ? ws->ln_parts : nullptr;
         TRY(linear(R, H, w->Gp, xp, w->Gp, dt, w->in_w, w->Gp, w->in_b, ws->h, H, STDIFF_F32, STDIFF_EPI_BIAS, nullptr, 0,
                    nullptr, 0, stream));
