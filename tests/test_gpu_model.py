@@ -450,7 +450,7 @@ def test_errors_and_quirks():
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-@pytest.mark.parametrize("H,heads", [(128, 4), (256, 4), (384, 6), (512, 8), (2048, 16)])
+@pytest.mark.parametrize("H,heads", [(128, 4), (256, 4), (384, 6), (512, 8), (2048, 16), (4096, 32)])
 def test_fused_ln_forward_against_unfused(dtype, H, heads, monkeypatch):
     """The fused-LN form of the denoiser forward (LayerNorm + modulate as the epilogue of the adaLN GEMM, no [R, 6H]
     modulation matrix) against the plain form (STDIFF_FUSED_LN=0).  H = 128, 384: every LayerNorm's statistics come from
@@ -461,6 +461,8 @@ def test_fused_ln_forward_against_unfused(dtype, H, heads, monkeypatch):
     from stdiff_amd import engine as E
     from stdiff_amd.model.stDiff_model import DiT_stDiff
     from stdiff_amd.model.stDiff_scheduler import NoiseScheduler
+    if H == 4096 and dtype == "bf16":
+        pytest.skip("hidden 4096 (16 parts per row > 8: statistics pass, bit-identical forms) is run once, in fp16")
     G, depth = 72, 2
     lens = [512] * 4 + [512, 300, 45]                      # 2905 rows, ragged
     R = sum(lens)
@@ -490,7 +492,7 @@ def test_fused_ln_forward_against_unfused(dtype, H, heads, monkeypatch):
                 assert one.slabs[0][2].fused
                 one.init()
                 assert torch.equal(one.run([49, 48, 47]), res[2560:2860])
-    if H % 256:
+    if H % 256 or H > 2048:
         assert torch.equal(outs["1"], outs["0"])
     else:
         e = relerr(outs["1"], outs["0"])
