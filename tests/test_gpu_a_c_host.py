@@ -1,0 +1,49 @@
+"""GPU: the C ABI as a C caller sees it.  examples/c_host/sample_host_* is a C++ program (hipMalloc'ed buffers, the
+entry points of include/stdiff_hip.h, no Python, no torch) that runs the whole sample_stDiff reverse loop from an
+export of the model's packed operands; its result must equal the Python path's BIT FOR BIT (same library, same launch
+sequence, same Philox stream).  The Python path itself is pinned by the oracle and the goldens in the other test files.
+
+Collected first on purpose: it starts a child GPU process, which this pool's boxes only allow from a young parent
+(DESIGN section 6a')."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cpu_ref as O  # noqa: E402
+
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("dtype,H,heads", [("fp16", 256, 4), ("bf16", 128, 4), ("fp32", 128, 2), ("fp16", 512, 8)])
+def test_c_host_reverse_loop_equals_python(dtype, H, heads, tmp_path):
+    from stdiff_amd.export import export_for_c_host
+    from stdiff_amd.model.sample import sample_stDiff
+    from stdiff_amd.model.stDiff_model import DiT_stDiff
+    from stdiff_amd.model.stDiff_scheduler import NoiseScheduler
+    from stdiff_amd.process.data import get_data_loader
+    exe = os.path.join(ROOT, "examples", "c_host", "sample_host_f16" if dtype == "fp16" else "sample_host_bf16")
+    assert os.path.isfile(exe), "examples/c_host was not built (python -c 'import __graft_entry__ as g; g.build()')"
+    N, G, depth, B, T, seed = 1200, 72, 2, 512, 12, 20261111
+    p = O.make_params(G, H, depth, 33)
+    m = DiT_stDiff(G, H, depth, 'dit', heads, 6, compute_dtype=dtype)
+    m.load_state_dict(p)
+    m = m.to(DEV).eval()
+    mask = O.kfold_mask(G, 2)
+    gt = ((O.synth_expression(N, G, 9) * mask) * 2 - 1).astype(np.float32)
+    sched = NoiseScheduler(T, beta_schedule="cosine")
+    export_for_c_host(m, sched, gt, gt, mask, str(tmp_path), seed, chunk=B)
+    dl = get_data_loader(gt, gt, batch_size=B, is_shuffle=False)
+    want = sample_stDiff(m, dl, sched, mask=mask, gt=gt, device=torch.device(DEV), num_step=T, sample_shape=(N, G),
+                         is_condi=True, sample_intermediate=T, model_pred_type='noise', seed=seed, is_tqdm=False)
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    got = np.fromfile(os.path.join(str(tmp_path), "result.bin"), dtype=np.float32).reshape(N, G)
+    known = mask.astype(bool)
+    assert np.array_equal(got[:, known], gt[:, known])
+    assert np.array_equal(got, want), float(np.abs(got - want).max())
