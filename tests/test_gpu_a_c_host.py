@@ -28,6 +28,8 @@ def test_c_host_reverse_loop_equals_python(dtype, H, heads, tmp_path):
     from stdiff_amd.model.stDiff_scheduler import NoiseScheduler
     from stdiff_amd.process.data import get_data_loader
     exe = os.path.join(ROOT, "examples", "c_host", "sample_host_f16" if dtype == "fp16" else "sample_host_bf16")
+    if not os.path.isfile(exe):          # normally built by __graft_entry__.build(); the same image has hipcc
+        subprocess.run(["make", "-C", os.path.dirname(exe)], check=True, capture_output=True, timeout=300)
     assert os.path.isfile(exe), "examples/c_host was not built (python -c 'import __graft_entry__ as g; g.build()')"
     N, G, depth, B, T, seed = 1200, 72, 2, 512, 12, 20261111
     p = O.make_params(G, H, depth, 33)
