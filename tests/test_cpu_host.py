@@ -49,8 +49,40 @@ def test_struct_layouts_match_header():
         return out
     for cname, cls in (("stdiff_gemm_args", _lib.GemmArgs), ("stdiff_step_args", _lib.StepArgs),
                        ("stdiff_block_weights", _lib.BlockWeights), ("stdiff_dit_weights", _lib.DitWeights),
-                       ("stdiff_dit_workspace", _lib.DitWorkspace), ("stdiff_adamw_args", _lib.AdamWArgs)):
-        assert fields(cname) == [f[0] for f in cls._fields_], cname
+                       ("stdiff_dit_workspace", _lib.DitWorkspace), ("stdiff_adamw_args", _lib.AdamWArgs),
+                       ("stdiff_train_linear", _lib.TrainLinear), ("stdiff_train_block", _lib.TrainBlock),
+                       ("stdiff_train_weights", _lib.TrainWeights), ("stdiff_train_block_acts", _lib.TrainBlockActs),
+                       ("stdiff_train_acts", _lib.TrainActs)):
+        assert fields(cname) == [f[0].rstrip("_") if f[0] == "in_" else f[0] for f in cls._fields_], cname
+
+
+def test_struct_sizes_and_offsets_match_a_c_compiler(tmp_path):
+    """The header is plain C: gcc's sizeof / offsetof of every struct field against the ctypes mirrors (a mirror whose
+    field types drift from the header would still have the right names)."""
+    import subprocess
+    from stdiff_amd import _lib
+    pairs = (("stdiff_gemm_args", _lib.GemmArgs), ("stdiff_step_args", _lib.StepArgs),
+             ("stdiff_block_weights", _lib.BlockWeights), ("stdiff_dit_weights", _lib.DitWeights),
+             ("stdiff_dit_workspace", _lib.DitWorkspace), ("stdiff_adamw_args", _lib.AdamWArgs),
+             ("stdiff_train_linear", _lib.TrainLinear), ("stdiff_train_block", _lib.TrainBlock),
+             ("stdiff_train_weights", _lib.TrainWeights), ("stdiff_train_block_acts", _lib.TrainBlockActs),
+             ("stdiff_train_acts", _lib.TrainActs))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "stdiff_hip.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for f in cls._fields_:
+            cf = "in" if f[0] == "in_" else f[0]
+            lines.append(f'  printf("{cname}.{f[0]} %zu\\n", offsetof({cname}, {cf}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs:
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for f in cls._fields_:
+            assert int(got[f"{cname}.{f[0]}"]) == getattr(cls, f[0]).offset, (cname, f[0])
 
 
 def test_no_cpu_fallback():
