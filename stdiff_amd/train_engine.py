@@ -439,7 +439,11 @@ class TrainEngine(TrainCore):
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.pg = process_group
+        self.dist = None
         self.world = 1
+        # issue the per-bucket all-reduces even in a one-rank group (they are identities there): lets a single GPU
+        # execute the stream-ordered RCCL bucket path (tests)
+        self.force_buckets = os.environ.get("STDIFF_DDP_FORCE_BUCKETS") == "1"
         if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             import torch.distributed as dist
             self.dist = dist
@@ -495,7 +499,7 @@ class TrainEngine(TrainCore):
             else:
                 torch.cuda.synchronize(self.device)      # gloo + CUDA tensors behind a busy stream stalled on this stack
                 self.dist.all_reduce(self.flat_g[lo:hi], group=self.pg)
-        self.backward(a, after_bucket=reduce_bucket if self.world > 1 else None)       # :77
+        self.backward(a, after_bucket=reduce_bucket if (self.world > 1 or (self.force_buckets and self.dist is not None)) else None)       # :77
         for h in handles:
             h.wait()
         self.sumsq.zero_()

@@ -421,6 +421,54 @@ def test_ddp_train_step_two_ranks_golden(golden_dir, backend):
         assert status == "ok", f"rank {rank}: {info}"
 
 
+def test_rccl_bucket_path_on_one_rank(golden_dir, monkeypatch):
+    """The data-parallel step's RCCL branch (backend "nccl": every gradient bucket all-reduced asynchronously on RCCL's
+    stream as the backward pass completes it, handles waited before the gradient norm) on the ONE GPU this pool's boxes
+    have: a one-rank RCCL group, buckets forced (STDIFF_DDP_FORCE_BUCKETS=1; each all-reduce is an identity), three G6
+    iterations.  Transport between GPUs is not exercised; the stream ordering, the bucket hooks of the C-ABI backward
+    and the communicator calls are."""
+    import socket
+    import torch.distributed as dist
+    from stdiff_amd.train_engine import TrainEngine
+    monkeypatch.setenv("STDIFF_DDP_FORCE_BUCKETS", "1")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        g = np.load(os.path.join(golden_dir, "g6_train.npz"))
+        C, G, H, depth, heads, seed, T = [int(v) for v in g["cfg"]]
+        m, _ = build(G, H, depth, heads, seed, "fp32")
+        te = TrainEngine(m, lr=float(g["lr"][0]), diffusion_step=T, mask=g["mask"])
+        assert te.world == 1 and te.async_buckets and te.force_buckets
+        calls = []
+        real = dist.all_reduce
+
+        def spy(t, *a, **kw):
+            calls.append((t.numel(), kw.get("async_op", False)))
+            return real(t, *a, **kw)
+        monkeypatch.setattr(te.dist, "all_reduce", spy)
+        x, xc = torch.from_numpy(g["x"]).to(DEV), torch.from_numpy(g["x_cond"]).to(DEV)
+        for i in range(3):
+            loss, gn = te.step(x[i * C:(i + 1) * C].contiguous(), xc[i * C:(i + 1) * C].contiguous(),
+                               noise=torch.from_numpy(g["noise"][i]).to(DEV),
+                               timesteps=torch.from_numpy(g["timesteps"][i]).to(DEV))
+            assert abs(float(loss) - g["loss"][i]) < 1e-5 * max(1.0, g["loss"][i]), i
+            assert abs(float(gn) - g["gnorm"][i]) < 1e-4 * g["gnorm"][i], i
+        assert len(calls) == 3 * (depth + 2) and all(a for _, a in calls)
+        assert sum(n for n, _ in calls[:depth + 2]) == te.total          # the buckets cover the flat gradient once
+        sd = m.state_dict()
+        for k in g.files:
+            if k.startswith("post/"):
+                tol = 2e-3 if k.endswith("qkv.bias") else (2e-4 if k.endswith("time_emb.mlp.0.weight") else 2e-5)
+                assert relerr(sd[k[5:]], g[k]) < tol, k
+    finally:
+        dist.destroy_process_group()
+
+
 def test_fp16_sampling_tolerance_on_trained_weights():
     """Train from the reference initialisation (zero adaLN / output layers, Xavier elsewhere) for 60 epochs, then run
     the denoiser with fp16 operands on the TRAINED weights: the per-call error against the oracle stays inside 1e-3
