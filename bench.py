@@ -260,7 +260,7 @@ def train_throughput(dtype, dev, g=G, h=H, steps=20, warmup=5, dist=None, rank=0
     eng = TrainEngine(model, lr=1e-4, diffusion_step=T, mask=O.kfold_mask(g, 0))
     assert eng.world == world
     st = torch.from_numpy(O.synth_expression(8 * BATCH, g, 1 + rank) * 2 - 1).to(dev)
-    graph = world == 1                     # one hipGraph per iteration (parallel dW branches); DDP steps are eager
+    graph = world == 1 and dist is None    # one hipGraph per iteration (parallel dW branches); DDP steps are eager
     for i in range(warmup):
         eng.step(st[:BATCH], st[:BATCH], use_graph=graph)
     torch.cuda.synchronize()
@@ -338,7 +338,20 @@ def main():
         faulthandler.dump_traceback_later(int(os.environ["STDIFF_BENCH_DUMP"]), exit=False)
     if rehearsal:
         local = 0
-    if world > 1:
+    # STDIFF_BENCH_FORCE_DIST=1 with --gpus 1: the N-rank code path (RCCL process group, barriers, max-over-ranks, the
+    # data-parallel training leg with its bucketed all-reduces) in a ONE-rank RCCL group -- what a one-GPU box can
+    # execute of it.  Numbers of the sampling leg are unaffected; the training leg is the eager data-parallel step.
+    force_dist = world == 1 and os.environ.get("STDIFF_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ["STDIFF_DDP_FORCE_BUCKETS"] = "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if rehearsal:
             dist.init_process_group("gloo")
@@ -429,7 +442,7 @@ def main():
     del smp
     eng._ws.clear()
     torch.cuda.empty_cache()
-    if world == 1:
+    if world == 1 and not force_dist:
         if not args.no_alt and not args.no_graph:
             for alt, st_, wu in (("bf16", 5, 1), ("fp32", 2, 0)):
                 if alt != args.dtype:
@@ -443,7 +456,7 @@ def main():
         if not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
     failed = False
-    if world > 1 and not args.no_train:
+    if (world > 1 or force_dist) and not args.no_train:
         # secondary metric on N ranks: data-parallel training.  A watchdog on every rank guarantees that rank 0 still
         # prints its line should a collective ever stall -- with the leg marked failed and a NON-ZERO exit status.
         import threading
