@@ -441,7 +441,7 @@ def test_masked_mse(ops):
 
 
 @pytest.mark.parametrize("tdt", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M", [512, 2048 + 37])
+@pytest.mark.parametrize("M", [1, 100, 512, 2048 + 37])
 def test_gemm_ln_mod_epilogue_equals_unfused(tdt, M):
     """STDIFF_EPI_LN_MOD: the adaLN projection whose epilogue applies the LayerNorm + modulate it feeds must give, bit
     for bit, what the plain GEMM into a 16-bit [M, 2H] buffer followed by stdiff_ln_modulate gives (and that pair is
