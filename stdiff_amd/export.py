@@ -41,3 +41,25 @@ def export_for_c_host(model, sched, x_cond, gt, mask, path, seed, chunk=512):
         lines.append(f"{n} {raw.numel() * raw.element_size()}")
     with open(os.path.join(path, "manifest.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
+
+
+def export_train_for_c_host(engine, batches, path):
+    """Training counterpart: the flat fp32 parameter buffer of a TrainEngine (fp32 compute) with the offset of every
+    tensor, the noise-schedule tables, the hyper-parameters and `batches` = [(x, x_cond, noise, timesteps), ...];
+    examples/c_host/train_host.cpp runs the iterations and writes the updated flat buffer."""
+    os.makedirs(path, exist_ok=True)
+    assert engine.tdt == torch.float32, "the C++ training host is written for the fp32 path"
+    lines = [f"G = {engine.G}", f"Gp = {engine.Gp}", f"H = {engine.H}", f"heads = {engine.heads}",
+             f"depth = {engine.depth}", f"T = {engine.T}", f"total = {engine.total}", f"steps = {len(batches)}",
+             f"C = {batches[0][0].shape[0]}", f"lr_e12 = {int(round(engine.lr * 1e12))}"]
+    for n in engine.names:
+        lines.append(f"off.{n} = {engine.offs[n]}")
+    tensors = {"flat_p": engine.flat_p, "mask": engine.mask, "sa": engine.sa, "sb": engine.sb, "freqs": engine.pw.freqs}
+    for i, (x, xc, noise, t) in enumerate(batches):
+        tensors[f"x{i}"], tensors[f"xc{i}"], tensors[f"noise{i}"], tensors[f"t{i}"] = x, xc, noise, t
+    for n, t in tensors.items():
+        raw = t.detach().contiguous().cpu()
+        raw.numpy().tofile(os.path.join(path, n + ".bin"))
+        lines.append(f"{n} {raw.numel() * raw.element_size()}")
+    with open(os.path.join(path, "manifest.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")

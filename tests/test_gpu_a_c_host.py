@@ -49,3 +49,50 @@ def test_c_host_reverse_loop_equals_python(dtype, H, heads, tmp_path):
     known = mask.astype(bool)
     assert np.array_equal(got[:, known], gt[:, known])
     assert np.array_equal(got, want), float(np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("G", [72, 50])
+def test_c_host_training_iterations_equal_python(G, tmp_path):
+    """examples/c_host/train_host: three reference training iterations (add-noise + splice, stdiff_dit_train_forward,
+    masked MSE, stdiff_dit_backward, gradient norm, clip + AdamW) driven from C++ on an export of the flat parameter
+    buffer, against TrainEngine.step on the same batches, noise and timesteps (fp32 compute; G = 50 takes the
+    transposed-copy path of odd gene counts).  Gradients are bit-identical by construction (same launches); loss and
+    gradient norm are summed with float atomics, so the comparison allows their last bits where clipping applies."""
+    from stdiff_amd.export import export_train_for_c_host
+    from stdiff_amd.model.stDiff_model import DiT_stDiff
+    from stdiff_amd.train_engine import TrainEngine
+    exe = os.path.join(ROOT, "examples", "c_host", "train_host")
+    if not os.path.isfile(exe):
+        subprocess.run(["make", "-C", os.path.dirname(exe)], check=True, capture_output=True, timeout=300)
+    H, depth, heads, T, C, steps = 128, 2, 4, 1000, 96, 3
+    p = O.make_params(G, H, depth, 51)
+    m = DiT_stDiff(G, H, depth, 'dit', heads, 6, compute_dtype="fp32")
+    m.load_state_dict(p)
+    m = m.to(DEV)
+    mask = O.kfold_mask(G, 1)
+    te = TrainEngine(m, lr=1e-4, diffusion_step=T, mask=mask)
+    st = (O.synth_expression(steps * C, G, 8) * 2 - 1).astype(np.float32)
+    gen = torch.Generator().manual_seed(G)
+    batches = []
+    for i in range(steps):
+        x = torch.from_numpy(st[i * C:(i + 1) * C])
+        batches.append((x, (x * torch.from_numpy(mask)).float(), torch.randn(C, G, generator=gen),
+                        torch.randint(1, T, (C,), generator=gen)))
+    export_train_for_c_host(te, batches, str(tmp_path))
+    losses, norms = [], []
+    for x, xc, noise, tt in batches:
+        loss, gn = te.step(x.to(DEV), xc.to(DEV), noise=noise.to(DEV), timesteps=tt.to(DEV))
+        losses.append(float(loss))
+        norms.append(float(gn))
+    want = te.flat_p.cpu().numpy()
+    r = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    got = np.fromfile(os.path.join(str(tmp_path), "result.bin"), dtype=np.float32)
+    got_loss = np.fromfile(os.path.join(str(tmp_path), "loss.bin"), dtype=np.float32)
+    assert got.shape == want.shape
+    assert np.allclose(got_loss, losses, rtol=1e-5, atol=0)
+    if max(norms) < 1.0:                        # no clipping: the update does not see the norm's last bits
+        assert np.array_equal(got, want), float(np.abs(got - want).max())
+    else:
+        assert float(np.abs(got - want).max()) <= 1e-4 * float(np.abs(want).max())
+    assert float(np.abs(want - np.fromfile(os.path.join(str(tmp_path), "flat_p.bin"), dtype=np.float32)).max()) > 1e-5
