@@ -248,6 +248,41 @@ def cpu_baseline(rows_chunks=8, steps=10):
             "train_sample": f"{tsteps} training iterations of {BATCH} cells (forward, masked MSE, backward, clip, AdamW)"}
 
 
+def parity_check(dev, p=None):
+    """Part of the cpu_baseline leg (the only place bench.py touches the oracle): ONE chunk of 512 spots of the
+    workload's model through the HIP denoiser in the headline format (fp16 operands) and in fp32, against the oracle, in
+    the two forms north_star's tolerance can be read: max|a-b| / max|b| and the fraction of elements within
+    rtol |b| + atol with atol = rtol x max|b| (rtol 1e-3 for the 16-bit format, 1e-5 for fp32)."""
+    import numpy as np
+    from oracle import cpu_ref as O
+    from stdiff_amd.model.stDiff_model import DiT_stDiff
+    p = p or O.make_params(G, H, DEPTH, seed=1)
+    mask = O.kfold_mask(G, 0)
+    gt = torch.from_numpy((O.synth_expression(BATCH, G, 3) * mask) * 2 - 1)
+    g = torch.Generator().manual_seed(2)
+    m = torch.from_numpy(mask)
+    x = torch.randn(BATCH, G, generator=g) * (1 - m) + gt * m
+    t = torch.full((BATCH,), 431, dtype=torch.int64)
+    with torch.no_grad():
+        ref = O.dit_forward(p, x, t, gt, HEADS, DEPTH).numpy().astype(np.float64)
+    out = {"sample": f"one chunk of {BATCH} spots x {G} genes, t = 431, against the oracle (CPU fp32)"}
+    scale = float(np.abs(ref).max())
+    for dt, rtol in (("fp16", 1e-3), ("fp32", 1e-5)):
+        mdl = DiT_stDiff(G, H, DEPTH, 'dit', HEADS, 6, compute_dtype=dt)
+        mdl.load_state_dict(p)
+        mdl = mdl.to(dev).eval()
+        with torch.no_grad():
+            got = mdl(x, t, gt).cpu().numpy().astype(np.float64)
+        d = np.abs(got - ref)
+        out[dt + "_rel"] = float(d.max() / scale)
+        out[dt + "_rtol"] = rtol
+        out[dt + "_frac_within_rtol_b_plus_atol"] = float((d <= rtol * np.abs(ref) + rtol * scale).mean())
+        out[dt + "_frac_atol_tenth"] = float((d <= rtol * np.abs(ref) + 0.1 * rtol * scale).mean())
+        del mdl
+    torch.cuda.empty_cache()
+    return out
+
+
 def train_throughput(dtype, dev, g=G, h=H, steps=20, warmup=5, dist=None, rank=0, world=1):
     """train cells/s = cells through one full iteration (add-noise, forward, masked MSE, backward,
     clip, AdamW, operand repack) per second, steady state, reference batch of 512 cells PER RANK.
@@ -361,21 +396,23 @@ def main():
     dev = torch.device(f"cuda:{local}")
 
     from stdiff_amd import synth as O         # synthetic inputs (the oracle is imported by cpu_baseline() only)
-    from stdiff_amd import engine as E
     from stdiff_amd.model.stDiff_scheduler import NoiseScheduler
-    from stdiff_amd.parallel import shard_chunks
+    from stdiff_amd.parallel import ShardedSampler, shard_chunks
 
     model = build_model(args.dtype, dev)
     train_dtype = "bf16" if args.dtype == "fp16" else args.dtype     # fp16 is a sampling format; training stays bf16
     eng = model.engine()
     all_lens = [min(BATCH, args.spots - i) for i in range(0, args.spots, BATCH)]
-    lo, hi, lens = shard_chunks(all_lens, rank, world)               # this rank's contiguous run of chunks
-    R = hi - lo
     mask_np = O.kfold_mask(G, 0)
     mask = torch.from_numpy(mask_np).to(dev)
-    gt = O.synth_expression_device(R, G, 1 + rank, dev)
-    gt.mul_(mask).mul_(2).sub_(1)                                    # (st * mask) * 2 - 1   (test-stDiff.py:98-108)
     sched = NoiseScheduler(T, beta_schedule="cosine")
+
+    def fetch(lo, hi):
+        # this rank's rows of ONE spots x G matrix whose values depend on the global row only (the same input at any
+        # --gpus N), synthesised on the device: (st * mask) * 2 - 1   (test-stDiff.py:98-108)
+        g = O.synth_expression_device_rows(args.spots, G, 1, dev, lo, hi, BATCH)
+        g.mul_(mask).mul_(2).sub_(1)
+        return g, g
 
     def barrier():
         torch.cuda.synchronize()
@@ -383,39 +420,53 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    with torch.no_grad():
-        smp = E.LanedSampler(eng, sched, lens, gt, gt, mask, seed=1234, row_offset=lo,
-                             use_graph=not args.no_graph, lanes=args.lanes or None)
-        smp.init()
-        ts = list(range(T))[::-1]
-        left = [0]
+    # The PUBLIC sharded sampler (stdiff_amd/parallel.py: the object behind sample_stDiff_sharded): chunk-aligned shard
+    # of this rank, only its rows resident, no collective in the loop, noise keyed by the global row
+    smp = ShardedSampler(model, sched, mask, all_lens, fetch, seed=1234, use_graph=not args.no_graph,
+                         lanes=args.lanes or None)
+    lo, hi, lens = smp.lo, smp.hi, smp.lens
+    R = hi - lo
+    smp.init()
+    ts = list(range(T))[::-1]
+    left = [0]
 
-        def advance(n):          # n reverse steps; wraps to t = T-1 when the schedule is exhausted (timing only)
-            while n > 0:
-                if left[0] == 0:
-                    smp.run(ts[:1])
-                    left[0], n = T - 1, n - 1
-                k = min(n, left[0])
-                if k:
-                    smp.run_more(k)
-                left[0], n = left[0] - k, n - k
-        advance(1)               # setup: hipGraph capture + first replay (untimed)
-        advance(args.warmup)
-        barrier()
-        t0 = time.perf_counter()
-        advance(args.steps)
-        barrier()
-        dt = time.perf_counter() - t0
+    def advance(n):          # n reverse steps; wraps to t = T-1 when the schedule is exhausted (timing only)
+        while n > 0:
+            if left[0] == 0:
+                smp.run(ts[:1])
+                left[0], n = T - 1, n - 1
+            k = min(n, left[0])
+            if k:
+                smp.run_more(k)
+            left[0], n = left[0] - k, n - k
+    advance(1)               # setup: hipGraph capture + first replay (untimed)
+    advance(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    advance(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
     if dist is not None:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     assert bool(torch.isfinite(smp.x[:8192]).all()) and bool(torch.isfinite(smp.x[-8192:]).all()), "non-finite sample state"
+    # what lets the N-rank run be checked against N = 1: the state after these 1 + warmup + steps reverse steps does not
+    # depend on the sharding, so its checksum (sha256 over per-chunk integer sums of the fp32 bit patterns, all ranks in
+    # global chunk order) must be the same at every --gpus N; rccl_ranks = an all-reduce of ones over the process group
+    digest, xsum = smp.checksum()
+    ranks_seen = 1
+    if dist is not None:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
     ms_per_step = dt / args.steps * 1e3
     value = args.spots / (T * ms_per_step * 1e-3)
     step_flops = sum(n * flops_per_row(n) for n in all_lens)         # whole job, all ranks
-    slabs = smp.parts[0].slabs
-    lanes = len(smp.parts)
+    lsm = smp.smp                                                     # this rank's LanedSampler
+    slabs = lsm.parts[0].slabs
+    lanes = len(lsm.parts)
+    gt = smp.gt                                                       # this rank's known-gene rows [R, G]
 
     which = "BASELINE configs[3]" if (args.spots, G, H) == (SPOTS, 1024, 1024) else "configs[3] model at a reduced spot count"
     rec = {
@@ -431,6 +482,11 @@ def main():
                    "noise": "in-kernel Philox4x32-10", "lanes_per_gpu": lanes,
                    "row_slabs_per_lane": len(slabs), "rows_per_slab": slabs[0][1] - slabs[0][0]},
         "step_tflops": round(step_flops / (ms_per_step * 1e-3) / 1e12, 1),
+        "rccl_ranks": ranks_seen,
+        "shard_checksum": {"sha256_of_chunk_bit_sums": digest, "x_sum_f64": xsum,
+                           "after_reverse_steps": 1 + args.warmup + args.steps, "seed": 1234,
+                           "note": "independent of --gpus N and of lanes / slabs by construction: compare across runs "
+                                   "with equal --steps / --warmup / --spots / --dtype"},
     }
     if rank == 0:
         ws = max((sl[2] for sl in slabs), key=lambda w: w.R)         # a full slab's buffers (idle now)
@@ -444,7 +500,7 @@ def main():
     torch.cuda.empty_cache()
     if world == 1 and not force_dist:
         if not args.no_alt and not args.no_graph:
-            for alt, st_, wu in (("bf16", 5, 1), ("fp32", 2, 0)):
+            for alt, st_, wu in (("bf16", 5, 1), ("fp32", 5, 1)):
                 if alt != args.dtype:
                     rec[alt + "_operands"] = alt_sampling_leg(alt, dev, lens, gt, mask, sched, lo, args.spots, lanes, st_, wu)
         if not args.no_train:
@@ -455,6 +511,7 @@ def main():
             rec["train_cfg2_shape"] = train_throughput(train_dtype, dev, g=2000, h=2048, steps=10, warmup=3)
         if not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline()
+            rec["parity"] = parity_check(dev)
     failed = False
     if (world > 1 or force_dist) and not args.no_train:
         # secondary metric on N ranks: data-parallel training.  A watchdog on every rank guarantees that rank 0 still

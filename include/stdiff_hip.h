@@ -110,11 +110,19 @@ int stdiff_gemm(const stdiff_gemm_args* a, void* stream);
  * the fp32 partial products of a K-split go to a file-scope __device__ array inside the library (64 MiB per GPU the
  * library runs on, held until the process ends), whose per-device address is looked up once with
  * hipGetSymbolAddress on the first call on that device (make that first call outside stream capture).
- * Limit: 2 * M * round_up(N, 4) * 4 bytes must fit in the buffer, else STDIFF_ERR_SCRATCH and nothing is launched.
+ * Limit: a shape whose K axis the host would split (few 128 x 128 tiles, long K) needs at least 3 slices of
+ * M * round_up(N, 4) * 4 bytes in the buffer, else STDIFF_ERR_SCRATCH and nothing is launched; shapes that are not split
+ * (every GEMM with more tiles than a third of the CUs, e.g. the sampler's 131072-row launches) use no scratch and have
+ * no size limit here.
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) race; calls
  * on one stream are ordered.  Nothing in the array needs to start at zero (every slice is written before it is read). */
 #define STDIFF_STATIC_SCRATCH_BYTES (64u << 20)
 int stdiff_gemm_static_scratch(const stdiff_gemm_args* a, void* stream);
+
+/* The STDIFF_GEMM_TILE / _CUS / _SPLIT_TAIL and STDIFF_SPLITK_MAX / _BLOCKS / _MIN knobs (A/B timing, tests) are read
+ * from the environment once per process, at the first stdiff_gemm; this call reads them again.  No counterpart in the
+ * reference (a debugging hook).  Safe against concurrent launches (the record is swapped atomically). */
+void stdiff_reload_env(void);
 
 /* out[c, r] = in[r, c] for r < rows, and 0 for rows <= r < rows_pad (same dtype, ld_out >= rows_pad): turns the
  * TN / NN contractions of the backward pass (dW = dY^T X, dX = dY W) into NT GEMMs with a zero-padded K. */
@@ -171,7 +179,9 @@ int stdiff_gather_rows2(const float* a, int lda, const float* b, int ldb, const 
 /* Expression pre-processing per cell (test-stDiff.py:47-55: sc.pp.normalize_total(target_sum) -> sc.pp.log1p ->
  * scale() = MaxAbsScaler over the cell's genes, process/data.py:79-83), with data_augment's fixed offset
  * (process/data.py:86-100) as add_const:  y[r,:] = log1p((x[r,:] + add_const) * target_sum / rowsum) / rowmax.
- * Zero-sum / zero-max rows divide by 1.  fp32, y may alias x. */
+ * Zero-sum / zero-max rows divide by 1.  fp32, y may alias x.
+ * target_sum == 0: scale() alone (no normalize_total / log1p, add_const ignored): y[r,:] = x[r,:] / max|x[r,:]|, a true
+ * fp32 division as MaxAbsScaler performs it (bit-equal to the reference on fp32 input, golden G10). */
 int stdiff_preprocess_rows(const float* x, int ldx, float* y, int ldy, int R, int G, float add_const, float target_sum,
                            void* stream);
 

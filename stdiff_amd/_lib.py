@@ -103,6 +103,7 @@ _SIGS = {
     "stdiff_abi_version": (i32, []),
     "stdiff_h16_format": (i32, []),
     "stdiff_error_string": (C.c_char_p, [i32]),
+    "stdiff_reload_env": (None, []),
     "stdiff_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "stdiff_gemm_static_scratch": (i32, [C.POINTER(GemmArgs), vp]),
     "stdiff_transpose": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
@@ -168,6 +169,12 @@ def lib(fp16=False):
             raise RuntimeError(f"{base} was built with the wrong 16-bit operand format")
         _libs[bool(fp16)] = L
     return L
+
+
+def reload_env():
+    """Make the loaded libraries re-read their STDIFF_GEMM_* / STDIFF_SPLITK_* knobs (they read the environment once)."""
+    for L in _libs.values():
+        L.stdiff_reload_env()
 
 
 def lib_for(*tensors):

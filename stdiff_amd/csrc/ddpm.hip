@@ -72,33 +72,46 @@ __device__ __forceinline__ float splice(float v, float m, float g) {
     return addf(mulf(v, subf(1.0f, m)), mulf(m, g));
 }
 
+// Rows are walked by the grid, column groups (4 genes) by the threads of a block: no 64-bit division per element, and
+// a thread's mask quad is loaded once.  With in-kernel noise (z_base == NULL: the throughput mode) a column
+// group whose four genes are all KNOWN (mask == 1) needs neither x, eps nor noise: x*(1-1) + 1*gt == gt for every finite
+// update, so the group is a copy of gt (10 of 18 bytes per element, no Philox / Box-Muller; 41 % of the groups at 20 %
+// held-out genes).  With injected noise (parity runs) every element goes through the reference's arithmetic.
 template <bool VEC, typename TP>
-__global__ __launch_bounds__(256) void ddpm_step_kernel(stdiff_step_args a) {
+__global__ __launch_bounds__(256) void ddpm_step_kernel(stdiff_step_args a, int cols_t) {
+    // the block's 256 threads form cols_t (a power of two) column lanes x 256 / cols_t rows
+    const int tx = threadIdx.x & (cols_t - 1), ty = threadIdx.x / cols_t, rpb = blockDim.x / cols_t;
     const int t = *a.t_dev;
     const float ca = a.coef[t * 5 + 0], cb = a.coef[t * 5 + 1], c1 = a.coef[t * 5 + 2], c2 = a.coef[t * 5 + 3],
                 sg = a.coef[t * 5 + 4];
     const int gq = (a.G + 3) >> 2;
-    const size_t total = (size_t)a.R * gq;
     const float* zb = a.z_base ? a.z_base + (size_t)(a.t_first - t) * (size_t)(a.z_rows > 0 ? a.z_rows : a.R) * a.G : nullptr;
     const bool pvec = VEC && (a.ldxp % 4 == 0);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int r = (int)(i / gq), cg = (int)(i % gq), c = cg * 4;
-        const int n = min(4, a.G - c);
-        const size_t off = (size_t)r * a.G + c;
-        f32x4 x = load4<VEC>(a.x + off, n), e = load4<VEC>(a.eps + off, n), g = load4<VEC>(a.gt + off, n),
-              m = load4<VEC>(a.mask + c, n), z = {0.f, 0.f, 0.f, 0.f}, o;
-        if (t > 0) z = zb ? load4<VEC>(zb + off, n) : normal4(a.seed, a.row_offset + r, (uint32_t)cg, (uint32_t)t);
+    for (int cg = tx; cg < gq; cg += cols_t) {
+        const int c = cg * 4, n = min(4, a.G - c);
+        const f32x4 m = load4<VEC>(a.mask + c, n);
+        const bool known = !zb && m[0] == 1.0f && (n < 2 || m[1] == 1.0f) && (n < 3 || m[2] == 1.0f) && (n < 4 || m[3] == 1.0f);
+        for (int r = blockIdx.x * rpb + ty; r < a.R; r += gridDim.x * rpb) {
+            const size_t off = (size_t)r * a.G + c;
+            const f32x4 g = load4<VEC>(a.gt + off, n);
+            f32x4 o = g;
+            if (!known) {
+                const f32x4 x = load4<VEC>(a.x + off, n), e = load4<VEC>(a.eps + off, n);
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                if (t > 0) z = zb ? load4<VEC>(zb + off, n) : normal4(a.seed, a.row_offset + r, (uint32_t)cg, (uint32_t)t);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float x0 = a.pred_type == 0
-                           ? fminf(fmaxf(subf(mulf(ca, x[j]), mulf(cb, e[j])), -1.0f), 1.0f)
-                           : e[j];
-            float mu = addf(mulf(c1, x0), mulf(c2, x[j]));
-            if (t > 0) mu = addf(mu, mulf(sg, z[j]));
-            o[j] = splice(mu, m[j], g[j]);
+                for (int j = 0; j < 4; ++j) {
+                    float x0 = a.pred_type == 0
+                                   ? fminf(fmaxf(subf(mulf(ca, x[j]), mulf(cb, e[j])), -1.0f), 1.0f)
+                                   : e[j];
+                    float mu = addf(mulf(c1, x0), mulf(c2, x[j]));
+                    if (t > 0) mu = addf(mu, mulf(sg, z[j]));
+                    o[j] = splice(mu, m[j], g[j]);
+                }
+            }
+            store4<VEC>(a.x + off, o, n);
+            if (a.xp) store4p((TP*)a.xp + (size_t)r * a.ldxp + c, o, n, pvec);
         }
-        store4<VEC>(a.x + off, o, n);
-        if (a.xp) store4p((TP*)a.xp + (size_t)r * a.ldxp + c, o, n, pvec);
     }
 }
 
@@ -215,8 +228,12 @@ extern "C" int stdiff_ddpm_step(const stdiff_step_args* a, void* stream) {
     if (a->R == 0) return STDIFF_OK;
     const bool vec = a->G % 4 == 0 && al16(a->x) && al16(a->eps) && al16(a->gt) && al16(a->mask) && al16(a->z_base) &&
                      al16(a->xp);
-    dim3 grid(ew_grid((size_t)a->R * ((a->G + 3) / 4)));
-    DISPATCH_VEC_TP(ddpm_step_kernel, vec, a->xp_dtype == STDIFF_BF16, grid, (hipStream_t)stream, *a);
+    const int gq = (a->G + 3) / 4;
+    int cols_t = 1;
+    while (cols_t < gq && cols_t < 256) cols_t <<= 1;
+    const int rpb = 256 / cols_t;
+    dim3 grid(std::min<size_t>(((size_t)a->R + rpb - 1) / rpb, (size_t)ew_grid((size_t)a->R * gq)));
+    DISPATCH_VEC_TP(ddpm_step_kernel, vec, a->xp_dtype == STDIFF_BF16, grid, (hipStream_t)stream, *a, cols_t);
     STDIFF_LAUNCH_STATUS();
     return STDIFF_OK;
 }

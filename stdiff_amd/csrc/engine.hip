@@ -19,7 +19,7 @@ extern "C" const char* stdiff_error_string(int s) {
         case STDIFF_ERR_SHAPE: return "shape not supported by the gfx950 kernels";
         case STDIFF_ERR_ALIGN: return "pointer or leading dimension not 16-byte aligned";
         case STDIFF_ERR_STATE: return "handle in the wrong state";
-        case STDIFF_ERR_SCRATCH: return "problem exceeds the library's static scratch buffer (2 * M * round_up(N, 4) * 4 bytes > STDIFF_STATIC_SCRATCH_BYTES)";
+        case STDIFF_ERR_SCRATCH: return "split-K problem exceeds the library's static scratch buffer (3 * M * round_up(N, 4) * 4 bytes > STDIFF_STATIC_SCRATCH_BYTES)";
         default: return s > 0 ? hipGetErrorString((hipError_t)s) : "unknown stdiff status";
     }
 }

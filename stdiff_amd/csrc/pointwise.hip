@@ -151,21 +151,28 @@ __global__ __launch_bounds__(256) void gather_rows2_kernel(const float* __restri
 //   [data_augment(fixed): + add_const]  ->  scanpy normalize_total(target_sum)  ->  log1p  ->  MaxAbsScaler over the
 //   cell's genes (scale() transposes, so the "feature" is the cell).  Zero-count cells divide by 1, as in scanpy /
 //   sklearn.  One wave per row, three sweeps (sum, max, write); the row is re-read from L2.
+// SCALE_ONLY: just scale() (process/data.py:79-83) on an already normalised matrix: y = x / max|x| per cell, a true
+// fp32 division like MaxAbsScaler's `X /= scale_` (bit-equal to sklearn on fp32 input; golden G10).
+template <bool SCALE_ONLY>
 __global__ __launch_bounds__(256) void preprocess_rows_kernel(const float* __restrict__ x, int ldx, float* y, int ldy,
                                                               int R, int G, float add_const, float target_sum) {
     const int lane = threadIdx.x & 63;
     for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += gridDim.x * 4) {
         const float* xr = x + (size_t)r * ldx;
-        float s = 0.f;
-        for (int c = lane; c < G; c += 64) s += xr[c] + add_const;
-        s = wave_sum(s);
-        const float k = target_sum / (s == 0.f ? 1.f : s);
+        float k = 1.f;
+        if constexpr (!SCALE_ONLY) {
+            float s = 0.f;
+            for (int c = lane; c < G; c += 64) s += xr[c] + add_const;
+            s = wave_sum(s);
+            k = target_sum / (s == 0.f ? 1.f : s);
+        }
+        auto value = [&](int c) { return SCALE_ONLY ? xr[c] : log1pf((xr[c] + add_const) * k); };
         float mx = 0.f;
-        for (int c = lane; c < G; c += 64) mx = fmaxf(mx, fabsf(log1pf((xr[c] + add_const) * k)));
+        for (int c = lane; c < G; c += 64) mx = fmaxf(mx, fabsf(value(c)));
         mx = wave_max(mx);
-        const float inv = 1.0f / (mx == 0.f ? 1.f : mx);
+        const float den = mx == 0.f ? 1.f : mx;
         float* yr = y + (size_t)r * ldy;
-        for (int c = lane; c < G; c += 64) yr[c] = log1pf((xr[c] + add_const) * k) * inv;
+        for (int c = lane; c < G; c += 64) yr[c] = value(c) / den;
     }
 }
 
@@ -264,11 +271,15 @@ extern "C" int stdiff_gather_rows2(const float* a, int lda, const float* b, int 
 
 extern "C" int stdiff_preprocess_rows(const float* x, int ldx, float* y, int ldy, int R, int G, float add_const,
                                       float target_sum, void* stream) {
-    STDIFF_CHECK_ARG(R >= 0 && G > 0 && target_sum > 0.f);
+    STDIFF_CHECK_ARG(R >= 0 && G > 0 && target_sum >= 0.f);
     if (R == 0) return STDIFF_OK;
     STDIFF_CHECK_ARG(x && y && ldx >= G && ldy >= G);
-    hipLaunchKernelGGL(preprocess_rows_kernel, dim3(std::min(cdiv(R, 4), 8192)), dim3(256), 0, (hipStream_t)stream, x, ldx,
-                       y, ldy, R, G, add_const, target_sum);
+    const dim3 grid(std::min(cdiv(R, 4), 8192)), block(256);
+    if (target_sum == 0.f)         // scale() alone: no normalize_total / log1p (add_const is ignored)
+        hipLaunchKernelGGL(preprocess_rows_kernel<true>, grid, block, 0, (hipStream_t)stream, x, ldx, y, ldy, R, G, 0.f, 0.f);
+    else
+        hipLaunchKernelGGL(preprocess_rows_kernel<false>, grid, block, 0, (hipStream_t)stream, x, ldx, y, ldy, R, G,
+                           add_const, target_sum);
     STDIFF_LAUNCH_STATUS();
     return STDIFF_OK;
 }

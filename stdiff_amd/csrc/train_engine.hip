@@ -8,6 +8,8 @@
 // projections (functions of SiLU(c) alone) go there as one chain.  Fork / join use a small pool of HIP events that the
 // library creates once per device (events hold no device memory); under stream capture they become graph edges.
 // No device memory is allocated here; every buffer comes from the caller.  Not thread-safe per device.
+#include <mutex>
+
 #include "common.h"
 
 #define TRY(expr)                           \
@@ -23,13 +25,19 @@
 
 namespace {
 constexpr int MAX_DEV = 16, MAX_DEPTH = 60, N_EV = MAX_DEPTH + 4;
+// The ONE piece of process-wide state of this file: the per-device pool of fork / join events (no device memory; made
+// on a device's first training enqueue, kept until the process ends).  Creation is serialised by a mutex, so two host
+// threads that enqueue on the same device for the first time find one pool; USING the pool is per device and not
+// thread-safe, like the rest of an enqueue (include/stdiff_hip.h: one enqueue per device at a time).
 hipEvent_t g_events[MAX_DEV][N_EV];
 bool g_events_ready[MAX_DEV];
+std::mutex g_events_mutex;
 
 int events_for_device(hipEvent_t** out) {
     int dev = 0;
     TRYH(hipGetDevice(&dev));
     if (dev < 0 || dev >= MAX_DEV) return STDIFF_ERR_ARG;
+    std::lock_guard<std::mutex> lock(g_events_mutex);
     if (!g_events_ready[dev]) {
         for (int i = 0; i < N_EV; ++i) TRYH(hipEventCreateWithFlags(&g_events[dev][i], hipEventDisableTiming));
         g_events_ready[dev] = true;

@@ -275,7 +275,12 @@ class DenoiserEngine:
         xp = ws.xp if xp is None else xp
         s = ws.s if s is None else s
         assert xp.shape == (ws.R, self.pw.Gp) and xp.is_contiguous() and s.shape == (ws.R, self.pw.H)
-        if ws.fused:
+        if ws.fused and self.pw.fused_stale:
+            # the rebuild is a run of torch kernels: recorded into a hipGraph it would replay on every step and race
+            # with the other lanes' graphs, so samplers bring the operands up to date BEFORE they capture
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("fused adaLN operands are stale inside a stream capture: call "
+                                   "PackedWeights.ensure_fused() before capturing")
             self.pw.ensure_fused()
         check(lib_for(xp).stdiff_dit_forward(C.byref(self.pw.struct), C.byref(ws.struct), ptr(xp), ptr(s),
                                        ptr(ws.eps), ws.eps.stride(0), stream()))
@@ -404,7 +409,8 @@ class ReverseSampler:
         afterwards that stream is ordered behind `cur`."""
         t_first, z = self._t_first, self._z
         if self.stream is None:
-            self.stream = torch.cuda.Stream(device=self.pw.device)
+            self.stream = lane_streams(self.pw.device, 1)[0]
+        self.pw.ensure_fused()               # eagerly, on the caller's stream, which every lane stream waits on below
         self.stream.wait_stream(cur)
         if self.graph is None or self._graph_z != (ptr(z), t_first):
             with torch.cuda.stream(self.stream):
@@ -455,6 +461,40 @@ def concurrent_streams(device, n, candidates=12, spin_us=500):
     return (chosen + spare + [torch.cuda.Stream(device=device) for _ in range(n)])[:n]
 
 
+# Streams of the samplers and trainers of this process, per device, made ONCE and shared by every object that needs a
+# stream of its own (lane graphs, the capture stream of a training iteration, its side stream).
+# Why they are not drawn afresh from torch's pool of 32 per object: a HIP stream that has carried a deep queue of graph
+# replays keeps its pool of completion signals (KFD interrupt events) for the life of the process, and once about 21
+# DIFFERENT streams of a process had done so, no new GPU process could start on that GPU: its hsa_init failed to create
+# its first event and ROCr's async-events thread dereferenced the null HsaEvent (SIGSEGV; scripts/diag/, DESIGN.md 6a').
+# A 5-fold run through both 16-bit formats made 30 such streams.  With the cache a process uses 2 (lanes) + 1 (side).
+_STREAMS = {}
+
+
+def _dev_index(device):
+    d = torch.device(device)
+    return d.index if d.index is not None else torch.cuda.current_device()
+
+
+def lane_streams(device, n):
+    """The `n` lane streams of `device` (concurrently dispatching, see concurrent_streams), the same ones at every call."""
+    key = (_dev_index(device), "lanes")
+    have = _STREAMS.get(key, [])
+    if len(have) < n:
+        have = _STREAMS[key] = concurrent_streams(device, max(n, 2))      # 2 from the start: the usual lane count
+    return have[:n]
+
+
+def aux_stream(device, name):
+    """A cached non-default stream of `device` for role `name` ('side': the weight-gradient branch of a captured
+    training iteration)."""
+    key = (_dev_index(device), name)
+    st = _STREAMS.get(key)
+    if st is None:
+        st = _STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def default_lanes(chunk_lens):
     """Concurrent lanes per device: 2 when each lane still fills the chip (STDIFF_LANES overrides)."""
     env = os.environ.get("STDIFF_LANES")
@@ -498,7 +538,7 @@ class LanedSampler:
         self.bounds = [(p.row_offset - row_offset, p.row_offset - row_offset + p.R) for p in self.parts]
         self.use_graph = use_graph
         if use_graph and len(self.parts) > 1:           # lane streams that really overlap (see concurrent_streams)
-            for p, st in zip(self.parts, concurrent_streams(engine.pw.device, len(self.parts))):
+            for p, st in zip(self.parts, lane_streams(engine.pw.device, len(self.parts))):
                 p.stream = st
 
     def init(self, x_T=None):

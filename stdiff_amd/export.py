@@ -1,6 +1,6 @@
 """Raw-file export of everything a C/C++ host needs to run the reverse loop through libstdiff_hip*.so without Python:
 the packed MFMA operands and biases of a DiT_stDiff, the scheduler's step coefficients and the inputs of one
-sample_stDiff call.  examples/c_host/sample_host.cpp reads it; tests/test_gpu_a_c_host.py compares the two results."""
+sample_stDiff call.  examples/c_host/sample_host.cpp reads it; tests/test_gpu_host_c.py compares the two results."""
 import os
 
 import numpy as np

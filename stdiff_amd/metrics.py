@@ -84,6 +84,38 @@ def spearman(x, y):
     return out
 
 
+def _degenerate_column(x, y):
+    """SSIM / RMSE / JS of ONE gene (float64 host vectors: x measured, y imputed) whose measured or imputed column is
+    constant or all zero.  There the reference's scaling step divides 0 by 0 and its `fillna(1e-20)`
+    (test-stDiff.py:285-286,332-333,356-357) decides the value: NaNs of the SCALED column become 1e-20.  The closed
+    forms of the device path do not cover that, and such genes are few, so they take this [N]-sized host route."""
+    def fill(v):
+        v = np.array(v, dtype=np.float64)
+        v[np.isnan(v)] = 1e-20
+        return v
+    out = {}
+    with np.errstate(all="ignore"):
+        a, b = fill(x / x.max()), fill(y / y.max())                                    # scale_max :223-228
+        M = b.max() if a.max() > b.max() else a.max()                                  # :287 (indexing a pair by a bool)
+        mu1, mu2 = a.mean(), b.mean()                                                  # cal_ssim :203-220
+        s1, s2 = np.sqrt(((a - mu1) ** 2).mean()), np.sqrt(((b - mu2) ** 2).mean())
+        s12 = ((a - mu1) * (b - mu2)).mean()
+        C1, C2 = (0.01 * M) ** 2, (0.03 * M) ** 2
+        C3 = C2 / 2
+        out["SSIM"] = ((2 * mu1 * mu2 + C1) / (mu1 ** 2 + mu2 ** 2 + C1)) * ((2 * s1 * s2 + C2) / (s1 ** 2 + s2 ** 2 + C2)) \
+            * ((s12 + C3) / (s1 * s2 + C3))
+        zx, zy = fill((x - x.mean()) / x.std()), fill((y - y.mean()) / y.std())        # scale_z_score :231-237
+        out["RMSE"] = np.sqrt(((zx - zy) ** 2).mean())                                 # :358
+        p, q = fill(x / x.sum()), fill(y / y.sum())                                    # scale_plus :240-245
+        m = (p + q) / 2                                                                # :334-335
+
+        def kl(pk, qk):                                                                # scipy.stats.entropy(pk, qk)
+            pk, qk = pk / pk.sum(), qk / qk.sum()
+            return np.where(pk > 0, pk * np.log(pk / qk), 0.0).sum()
+        out["JS"] = 0.5 * kl(p, m) + 0.5 * kl(q, m)
+    return out
+
+
 def gene_metrics(imputed, measured, js=True, spcc=True):
     """dict of per-gene float64 numpy vectors: PCC, cosine, SPCC, RMSE (after zscore), SSIM (after scale_max), JS
     (after scale_plus).  imputed / measured: [N, G] numpy or device tensors (raw = measured, impute = imputed in the
@@ -117,4 +149,14 @@ def gene_metrics(imputed, measured, js=True, spcc=True):
         for c in range(ch):
             acc += p[c]
         out["JS"] = acc
+    # constant / all-zero columns: the reference's fillna(1e-20) semantics (see _degenerate_column)
+    n = m["n"]
+    bad = np.flatnonzero((m["sxx"] - m["sx"] ** 2 / n <= 0) | (m["syy"] - m["sy"] ** 2 / n <= 0))
+    if bad.size:
+        idx = torch.from_numpy(bad).to(dev)
+        xc, yc = x[:, idx].double().cpu().numpy(), y[:, idx].double().cpu().numpy()
+        for k, g in enumerate(bad):
+            d = _degenerate_column(xc[:, k], yc[:, k])
+            for name in ("SSIM", "RMSE") + (("JS",) if js else ()):
+                out[name][g] = d[name]
     return out

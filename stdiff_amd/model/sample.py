@@ -58,7 +58,8 @@ def sample_stDiff(model,
     Returns a host float32 ndarray [N, G].  Keyword-only extras (not in the reference): ``x_T`` / ``step_noise``
     inject the initial draw [N,G] and the per-step draws [n_steps-ish, N, G] (row i is used at timestep
     timesteps[0]-i) for bit-reproducible parity runs; otherwise noise comes from an in-kernel Philox stream keyed
-    by ``seed`` (default: drawn from torch's global generator), the global row index and the timestep.  ``lanes``: concurrent chunk
+    by ``seed`` (default: one draw from torch's global CPU generator per call, which advances that generator),
+    the global row index and the timestep.  ``lanes``: concurrent chunk
     groups on separate HIP streams (default: engine.default_lanes; results do not depend on it)."""
     if not is_condi:
         raise ValueError("is_condi=False passes y=None to cond_layer (sample.py:13-14): unsupported by the reference "
@@ -85,6 +86,9 @@ def sample_stDiff(model,
         # one draw from the global generator per call: successive calls differ (as the reference's torch.randn draws
         # do) and torch.manual_seed still fixes the sequence
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        # NOT a collective: under a process group each rank that calls this samples ITS OWN matrix with its own
+        # draw (fold-parallel drivers call it a different number of times per rank).  Spot-sharded sampling of ONE
+        # matrix goes through parallel.sample_stDiff_sharded, whose seed is explicit and equal on every rank.
     with torch.no_grad():
         smp = E.LanedSampler(eng, noise_scheduler, lens, x_cond, gt_t, mask_t, pred_type=model_pred_type, seed=seed,
                              use_graph=use_graph, lanes=1 if step_noise is not None else lanes)

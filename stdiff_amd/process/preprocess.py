@@ -6,8 +6,10 @@ arrays out (the reference works on AnnData through scanpy / sklearn, which this 
     sc.pp.log1p
     scale(adata) = MaxAbsScaler().fit_transform(X.T).T  -> each cell divided by its largest |value|
 
-normalize_total, log1p and scale are one fused per-cell kernel (stdiff_preprocess_rows).  Parity note: scanpy is not
-importable here, so the check is a float64 numpy restatement of these documented semantics (tests), not the library."""
+normalize_total, log1p and scale are one fused per-cell kernel (stdiff_preprocess_rows); `scale` alone is the same
+kernel with the first two stages switched off.  Parity: scale() is pinned by the reference's own function run on
+sklearn (golden G10, bit-equal); scanpy is not importable here, so normalize_total / log1p are checked against a
+float64 numpy restatement of their documented semantics only (parity unpinned for those two stages)."""
 import numpy as np
 import torch
 
@@ -23,6 +25,20 @@ def normalize_log1p_scale(x, target_sum=1e4, add_const=0.0, out=None):
         out = torch.empty_like(x)
     check(lib().stdiff_preprocess_rows(ptr(x), x.stride(0), ptr(out), out.stride(0), x.shape[0], x.shape[1],
                                        float(add_const), float(target_sum), stream()))
+    return out
+
+
+def scale(x, out=None):
+    """scale() of the reference (process/data.py:79-83: MaxAbsScaler().fit_transform(X.T).T) alone: every cell divided
+    by its largest |value| (cells of zeros by 1), fp32 division as sklearn does it -- bit-equal to the reference on
+    fp32 input (golden G10).  x: fp32 [cells, genes] device tensor."""
+    require_gpu(x, out)
+    if x.dim() != 2 or x.dtype != torch.float32 or x.stride(1) != 1:
+        raise ValueError("x must be fp32 [cells, genes] with contiguous rows")
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().stdiff_preprocess_rows(ptr(x), x.stride(0), ptr(out), out.stride(0), x.shape[0], x.shape[1], 0.0, 0.0,
+                                       stream()))
     return out
 
 

@@ -1,5 +1,5 @@
 """Synthetic expression matrices and gene hold-out masks shaped like the reference driver's inputs
-(test-stDiff.py:47-55,73,92-108).  Host-side numpy only; used by bench.py, the tests and the golden generator."""
+(test-stDiff.py:47-55,73,92-108).  Host-side numpy (plus two on-device generators for bench.py); used by bench.py, the tests and the golden generator."""
 import numpy as np
 
 
@@ -55,4 +55,30 @@ def synth_expression_device(n, g, seed, device, block=65536):
         mx = k.abs().amax(1, keepdim=True)
         mx[mx == 0] = 1.0
         out[i:i + block] = k / mx
+    return out
+
+
+def synth_expression_device_rows(n_total, g, seed, device, lo, hi, chunk=512):
+    """Rows [lo, hi) of ONE n_total x g synthetic matrix, drawn on the device so that a row's values depend on its
+    GLOBAL index only -- not on which rank holds it or how many ranks there are (lo and hi must be multiples of `chunk`,
+    or n_total): every `chunk` rows are drawn from a generator seeded with (seed, global chunk index), on a tensor whose
+    shape that chunk has in every sharding.  bench.py's input at any --gpus N is therefore the same matrix, which is
+    what lets its shard checksum be compared across world sizes."""
+    import torch
+    assert (lo % chunk == 0) and (hi % chunk == 0 or hi == n_total) and 0 <= lo <= hi <= n_total
+    rng = np.random.default_rng(seed)
+    lam = torch.from_numpy(rng.lognormal(0.0, 1.0, size=g).astype(np.float32)).to(device)
+    s = torch.from_numpy(rng.lognormal(0.0, 0.5, size=n_total).astype(np.float32)[lo:hi].copy()).to(device)
+    gen = torch.Generator(device=device)
+    out = torch.empty((hi - lo, g), device=device, dtype=torch.float32)
+    for i in range(lo, hi, chunk):
+        j = min(i + chunk, hi)
+        gen.manual_seed((int(seed) << 32) + i // chunk)
+        k = torch.poisson(lam[None, :] * s[i - lo:j - lo, None], generator=gen)
+        tot = k.sum(1, keepdim=True)
+        tot[tot == 0] = 1.0
+        k = torch.log1p(k / tot * 1e4)
+        mx = k.abs().amax(1, keepdim=True)
+        mx[mx == 0] = 1.0
+        out[i - lo:j - lo] = k / mx
     return out

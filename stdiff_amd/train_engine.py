@@ -155,7 +155,8 @@ class TrainCore:
         if self.side_mode == 0 or (self.side_mode == 1 and not torch.cuda.is_current_stream_capturing()):
             return
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            from .engine import aux_stream
+            self._side = aux_stream(self.device, "side")      # one per device and process (engine.py, _STREAMS)
             self.ws_splitk_side = torch.empty(16 << 20, device=self.device, dtype=torch.float32)
         self._side_on = True
 
@@ -520,7 +521,8 @@ class TrainEngine(TrainCore):
                 noise=torch.empty((C, self.G), device=dev), t=torch.empty((C,), device=dev, dtype=torch.int64),
                 graph=None)
         if self._stream is None:
-            self._stream = torch.cuda.Stream(device=dev)       # the legacy default stream cannot be captured
+            from .engine import lane_streams
+            self._stream = lane_streams(dev, 1)[0]             # the legacy default stream cannot be captured
         cur = torch.cuda.current_stream()
         self._stream.wait_stream(cur)
         with torch.cuda.stream(self._stream):
@@ -555,14 +557,15 @@ class _DitFunction(torch.autograd.Function):
     def forward(ctx, core, x, t, y, *params):
         C = x.shape[0]
         a = core.acts(C)
-        ops.pack_rows(x, core.Gp, core.tdt, out=a["xp"])
-        ops.pack_rows(y, core.Gp, core.tdt, out=a["yp"])
         if a.get("in_autograd"):
-            # a forward of this batch size is still waiting for its backward: its saved activations must survive,
-            # so this call gets a buffer set of its own (which replaces the cached one)
+            # a forward of this batch size is still waiting for its backward: its saved activations (the packed
+            # inputs xp / yp included: the in / cond weight gradients read them) must survive, so this call gets a
+            # buffer set of its own (which replaces the cached one) BEFORE anything is written
             core._acts.pop(C, None)
             a = core.acts(C)
         a["in_autograd"] = True
+        ops.pack_rows(x, core.Gp, core.tdt, out=a["xp"])
+        ops.pack_rows(y, core.Gp, core.tdt, out=a["yp"])
         eps = core.forward(a, t)
         ctx.core, ctx.a = core, a
         return eps.clone()

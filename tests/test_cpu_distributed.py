@@ -34,8 +34,39 @@ def _worker(rank, world, port, q):
         lo, hi, mine = shard_chunks(lens, rank, world)
         assert sum(mine) == hi - lo
         local = np.arange(lo, hi, dtype=np.float32)[:, None] * np.ones((1, 3), dtype=np.float32)
-        full = gather_rows(local, sum(lens))
-        assert np.array_equal(full[:, 0], np.arange(sum(lens), dtype=np.float32))
+        full = gather_rows(local, sum(lens))                 # numpy in, numpy out; unequal shards (120 / 57 rows)
+        assert isinstance(full, np.ndarray) and np.array_equal(full[:, 0], np.arange(sum(lens), dtype=np.float32))
+        tfull = gather_rows(torch.from_numpy(local), sum(lens))          # tensor in, tensor out: ONE padded all_gather
+        assert torch.is_tensor(tfull) and torch.equal(tfull, torch.from_numpy(full))
+        # the host side of sample_stDiff_sharded: chunk lengths without touching the data, and ONLY this rank's rows
+        from torch.utils.data import DataLoader, TensorDataset
+        from stdiff_amd.parallel import combine_chunk_sums, loader_chunk_lens, loader_condition_rows
+        from stdiff_amd.process.data import get_data_loader
+        data = np.arange(sum(lens) * 3, dtype=np.float32).reshape(-1, 3)
+        dl = get_data_loader(data, data + 0.5, batch_size=40, is_shuffle=False)
+        assert loader_chunk_lens(dl) == lens
+        rows = loader_condition_rows(dl, lo, hi, "cpu")
+        assert rows.shape == (hi - lo, 3) and torch.equal(rows, torch.from_numpy(data[lo:hi] + 0.5))
+
+        class Odd:                                           # a loader that only iterates (no dataset / sampler)
+            def __iter__(self):
+                for i in range(0, len(data), 40):
+                    yield torch.from_numpy(data[i:i + 40]), torch.from_numpy(data[i:i + 40] + 0.5)
+        assert loader_chunk_lens(Odd()) == lens
+        assert torch.equal(loader_condition_rows(Odd(), lo, hi, "cpu"), rows)
+        dl_drop = DataLoader(TensorDataset(torch.from_numpy(data), torch.from_numpy(data)), batch_size=40, drop_last=True)
+        assert loader_chunk_lens(dl_drop) == [40] * 4
+        # per-chunk integer checksums combine to the same digest however the chunks were spread over ranks
+        sums = np.array([int(data[a:b].view(np.int32).astype(np.int64).sum()) for a, b in
+                         zip(np.cumsum([0] + lens[:-1]), np.cumsum(lens))], dtype=np.int64)
+        c_lo = sum(1 for i in range(len(lens)) if sum(lens[:i]) < lo)
+        mine_sums = torch.from_numpy(sums[c_lo:c_lo + len(mine)])
+        parts = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+        pad = torch.zeros(3, dtype=torch.int64)
+        pad[:len(mine)] = mine_sums
+        dist.all_gather(parts, pad)
+        counts = [len(shard_chunks(lens, r, world)[2]) for r in range(world)]
+        assert combine_chunk_sums(np.concatenate([parts[r][:counts[r]].numpy() for r in range(world)])) == combine_chunk_sums(sums)
 
         # ---- training: each rank = the reference step on ITS batch; flat grads all-reduced bucket by bucket
         g6 = np.load(os.path.join(GOLDEN, "g6_train.npz"))

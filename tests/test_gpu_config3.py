@@ -7,7 +7,8 @@ evaluates single chunks picked from it (first chunk, the chunks either side of a
   * a chunk's result depends on nothing but the chunk (attention is per chunk, noise is keyed by the global row):
     chunk k run alone == chunk k inside the full 2-lane, 8-slab run, bit for bit,
   * teacher-forced denoiser output of those chunks against the oracle: 1e-5 (fp32 path) / 1e-3 (fp16 operands) of the
-    output scale (max-norm relative error: max|a-b| / max|b|).
+    output scale (max-norm relative error: max|a-b| / max|b|); next to it the element-wise form of the same tolerance
+    is reported and asserted (conftest.elementwise: fraction of elements within rtol|b| + atol).
 Inputs are drawn on the device (a 4 GB host matrix would take minutes to synthesise); only the checked chunks travel
 to the host."""
 import numpy as np
@@ -99,6 +100,10 @@ def test_config3_chunks_against_oracle(dtype, progress):
             worst = max(worst, e)
             progress(f"configs[3] {dtype} chunk {k} ({hi - lo} rows): eps rel err {e:.3e}")
             assert e < tol, k
+            from conftest import elementwise_line
+            ew, line = elementwise_line(f"configs[3] {dtype} chunk {k}", eps[lo:hi].cpu().numpy(), ref.numpy(), tol)
+            progress(line)
+            assert ew["full"] == 1.0 and ew["tenth"] > 0.8, (k, ew)
             if dtype == "fp32" and k in (0, 1953):
                 z = torch.randn(hi - lo, G, generator=torch.Generator().manual_seed(k))
                 ref_x, _ = O.step(tb, ref, t, x_c, z)

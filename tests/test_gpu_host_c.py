@@ -3,8 +3,8 @@ entry points of include/stdiff_hip.h, no Python, no torch) that runs the whole s
 export of the model's packed operands; its result must equal the Python path's BIT FOR BIT (same library, same launch
 sequence, same Philox stream).  The Python path itself is pinned by the oracle and the goldens in the other test files.
 
-Collected first on purpose: it starts a child GPU process, which this pool's boxes only allow from a young parent
-(DESIGN section 6a')."""
+Starts child GPU processes; collected AFTER tests/test_gpu_folds.py (which used to leave the parent unable to start
+any: DESIGN section 6a', fixed in round 3 by the per-device stream cache)."""
 import os
 import subprocess
 

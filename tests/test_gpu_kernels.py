@@ -195,15 +195,15 @@ def test_gemm_k_major_operands(ops, L, dt, M, N, K):
 
 @pytest.mark.parametrize("variant", ["3", "4", "4s", "4h"])
 @pytest.mark.parametrize("M,N,K", [(600, 520, 256), (257, 264, 64), (1024, 512, 1024), (300, 1000, 192)])
-def test_gemm_256_kernel_all_epilogues(ops, L, M, N, K, variant, monkeypatch):
-    """The persistent 256 x 256 bf16 kernel forced (STDIFF_GEMM_TILE=3 is read per call): ragged M / N edges, every
+def test_gemm_256_kernel_all_epilogues(ops, L, M, N, K, variant, gemm_knobs):
+    """The persistent 256 x 256 bf16 kernel forced (STDIFF_GEMM_TILE=3 through the gemm_knobs fixture): ragged M / N edges, every
     epilogue kind, fp32 and bf16 outputs, K of 1 / 3 / 4 / 16 slabs (prologue and tail of the refill schedule).  Variant 3 =
     four 16-MFMA phases per slab, 4 = two 32-MFMA phases (the default), 4s = the same with the tiles of a short last
     round cut into 128-row half units (STDIFF_GEMM_SPLIT_TAIL=1; here every tile is in that round), 4h = the default
     kernel of the fp16 build (libstdiff_hip_f16.so)."""
-    monkeypatch.setenv("STDIFF_GEMM_TILE", variant[0])
-    if variant.endswith("s"):
-        monkeypatch.setenv("STDIFF_GEMM_SPLIT_TAIL", "1")
+    dt = "fp16" if variant.endswith("h") else "bf16"
+    L.lib(dt == "fp16")                                   # loaded before the knobs are published to it
+    gemm_knobs(STDIFF_GEMM_TILE=variant[0], **({"STDIFF_GEMM_SPLIT_TAIL": "1"} if variant.endswith("s") else {}))
     dt = "fp16" if variant.endswith("h") else "bf16"
     t16 = 6e-4 if dt == "fp16" else 5e-3          # one rounding of a 16-bit result
     A, W, b = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=K ** -0.5), rnd(N, seed=13, scale=0.1)
@@ -232,10 +232,29 @@ def test_gemm_256_kernel_all_epilogues(ops, L, M, N, K, variant, monkeypatch):
     assert relerr(o1, F.gelu(v)) < t16 and relerr(o2, v) < t16
 
 
-def test_gelu_polynomial_accuracy(ops, L, monkeypatch):
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_gemm_192t_equals_256q(ops, L, gemm_knobs, dt):
+    """gemm192t_kernel (192 x 256 tile, the previous tile leaves during the next tile's K loop; opt-in with
+    STDIFF_GEMM_TILE=5, profiles/notes/r03_gemm192t.md) against gemm256q_kernel: the same bits -- ragged M / N edges, with
+    and without bias, bias and GELU epilogues, K of 13 and 64 slabs, and a shape that walks several tiles per CU (the
+    pipelined path: operand ring and bias across tile boundaries)."""
+    L.lib(dt == "fp16")
+    for (M, N, K) in [(192, 256, 832), (1000, 520, 832), (777, 1032, 4096), (30000, 3072, 1024)]:
+        A, W, b = to_dt(rnd(M, K, seed=31), dt), to_dt(rnd(N, K, seed=32, scale=K ** -0.5), dt), rnd(N, seed=33).to(DEV)
+        for epi in (L.EPI_BIAS, L.EPI_GELU):
+            for bias in (b, None):
+                gemm_knobs(STDIFF_GEMM_TILE="4")
+                ref = ops.gemm(A, W, bias, epi=epi)
+                gemm_knobs(STDIFF_GEMM_TILE="5")
+                got = torch.full_like(ref, float("nan"))
+                ops.gemm(A, W, bias, out=got, epi=epi)
+                assert torch.equal(ref.view(torch.int16), got.view(torch.int16)), (M, N, K, epi, bias is not None)
+
+
+def test_gelu_polynomial_accuracy(ops, L, gemm_knobs):
     """gelu_poly4 (bf16 outputs of the 256 x 256 kernel) against erf GELU over the whole input range: the result,
     read back as bf16, is within one bf16 ulp of the correctly rounded value."""
-    monkeypatch.setenv("STDIFF_GEMM_TILE", "3")
+    gemm_knobs(STDIFF_GEMM_TILE="3")
     M, K = 512, 64
     A = torch.zeros(M, K)
     W = torch.zeros(256, K)

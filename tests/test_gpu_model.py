@@ -55,6 +55,11 @@ def test_forward_golden(golden_dir, case, dtype):
     e = relerr(eps, g["eps"])
     print(f"forward {case} {dtype}: rel err {e:.3e}")
     assert e < TOL[dtype]
+    if dtype != "bf16":            # the two formats that conform to north_star's rtol (1e-5 fp32 / 1e-3 16-bit)
+        from conftest import elementwise_line
+        ew, line = elementwise_line(f"G1 {case} {dtype}", eps.cpu().numpy(), g["eps"], TOL[dtype])
+        print(line)
+        assert ew["full"] == 1.0 and ew["tenth"] > 0.8, ew
     if dtype != "fp32":
         assert pearson_cols(eps.cpu().numpy(), g["eps"]).min() > 0.999
 
@@ -91,12 +96,19 @@ def test_sampling_teacher_forced(golden_dir, dtype):
     with torch.no_grad():
         smp = E.ReverseSampler(m.engine(), NoiseScheduler(T, beta_schedule="cosine"), lens, gt, gt,
                                torch.from_numpy(g["mask"]).to(DEV), use_graph=False)
-        worst = 0.0
+        worst, full, tenth = 0.0, 1.0, 1.0
+        from conftest import elementwise
         for i, t in enumerate(range(T - 1, -1, -1)):
             smp.set_x(torch.from_numpy(g["x_in"][i]).to(DEV))
-            worst = max(worst, relerr(smp.denoise_only(t), g["eps"][i]))
-    print(f"teacher-forced per-step eps {dtype}: worst rel err {worst:.3e}")
+            eps = smp.denoise_only(t)
+            worst = max(worst, relerr(eps, g["eps"][i]))
+            ew = elementwise(eps.cpu().numpy(), g["eps"][i], TOL[dtype])
+            full, tenth = min(full, ew["full"]), min(tenth, ew["tenth"])
+    print(f"teacher-forced per-step eps {dtype}: worst rel err {worst:.3e}; worst step's fraction of elements within "
+          f"rtol|b| + atol: {100 * full:.3f} % (atol = rtol x scale), {100 * tenth:.3f} % (atol = 0.1 rtol x scale)")
     assert worst < TOL[dtype]
+    if dtype != "bf16":
+        assert full == 1.0 and tenth > 0.8
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -255,6 +267,67 @@ def test_sampler_world_size_invariance():
             E.LanedSampler(m.engine(), ns, lens, gt, gt, mask, seed=7, lanes=2).run(ts, z=torch.zeros(T, N, G, device=DEV))
 
 
+def test_two_lane_graph_on_freshly_refreshed_weights():
+    """The fused-LN operand copies are rebuilt EAGERLY before any lane captures its hipGraph: a sampler that is the
+    first user of refreshed weights (nothing ran eagerly before it, as in sample_stDiff after training) gives the
+    1-lane eager result bit for bit with 2 lanes + graphs, the rebuild is in no graph, and a second weight change
+    between two runs of the same sampler is picked up."""
+    from stdiff_amd import engine as E
+    from stdiff_amd.model.stDiff_scheduler import NoiseScheduler
+    G, H, depth, heads, B, T = 64, 256, 2, 4, 64, 5
+    m, p = build(G, H, depth, heads, 11, "fp16")
+    eng = m.engine()
+    assert eng.pw.fused is not None
+    N = 6 * B + 9
+    mk = O.kfold_mask(G, 0)
+    mask = torch.from_numpy(mk).to(DEV)
+    gt = torch.from_numpy((O.synth_expression(N, G, 1) * mk) * 2 - 1).to(DEV)
+    ns = NoiseScheduler(T, beta_schedule="cosine")
+    ts = list(range(T))[::-1]
+    lens = [b - a for a, b in O.chunk_bounds(N, B)]
+
+    def run(lanes, graph):
+        eng.pw.refresh()                                   # what training / load_state_dict leave behind: stale copies
+        assert eng.pw.fused_stale
+        for t_ in eng.pw.fused.values():                   # make a missed rebuild visible
+            t_.fill_(float("nan")) if t_.dtype != torch.float32 else t_.zero_()
+        with torch.no_grad():
+            ls = E.LanedSampler(eng, ns, lens, gt, gt, mask, seed=3, lanes=lanes, use_graph=graph)
+            ls.init()
+            out = ls.run(ts).clone()
+        torch.cuda.synchronize()
+        assert not eng.pw.fused_stale
+        return out, ls
+    ref, _ = run(1, False)
+    assert bool(torch.isfinite(ref).all())
+    out, ls = run(2, True)
+    assert torch.equal(out, ref)
+    # the same sampler (graphs already captured) after another weight change
+    with torch.no_grad():
+        # (only the adaLN projections: the sampler hoisted cond_layer / time_emb results at construction)
+        sd = {k: (v * 1.01 if "adaLN" in k else v) for k, v in p.items()}
+        m.load_state_dict(sd)
+        eng.pw.refresh()
+        ls.init()
+        out2 = ls.run(ts).clone()
+        one = E.LanedSampler(eng, ns, lens, gt, gt, mask, seed=3, lanes=1, use_graph=False)
+        one.init()
+        ref2 = one.run(ts).clone()
+    assert torch.equal(out2, ref2) and not torch.equal(ref2, ref)
+    with pytest.raises(RuntimeError):                      # a stale rebuild can no longer be recorded into a graph
+        eng.pw.fused_stale = True
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            from stdiff_amd import ops
+            g = ops.Graph()
+            g.begin()
+            try:
+                eng.run(ls.parts[0].slabs[0][2], xp=ls.parts[0].xp[:ls.parts[0].slabs[0][1]])
+            finally:
+                g.end()
+    eng.pw.ensure_fused()
+
+
 def test_device_loader_matches_host_loader():
     """the device-resident loader yields the batches of the reference DataLoader (same seed -> same
     permutation, same partial last batch), epoch after epoch; rank/world shards whole batches; an unshuffled loader
@@ -374,6 +447,38 @@ def test_gene_metrics_match_scipy():
         assert np.allclose(got[k], ref[k], rtol=1e-9, atol=1e-10), (k, np.abs(got[k] - ref[k]).max())
     again = gene_metrics(imp, raw)                                     # numpy inputs, deterministic
     assert all(np.array_equal(again[k], got[k]) for k in got)
+
+
+def test_gene_metrics_match_reference_golden(golden_dir):
+    """SURVEY 8(f).3 pinned by the REFERENCE's own code: golden G9 = CalculateMeteics.SSIM / SPCC / JS / RMSE of
+    test-stDiff.py:254-364, executed from the reference's file by tools/make_goldens.py (imputed matrix through the CSV
+    round trip the reference uses) on tie-heavy count data with degenerate genes (measured all zero / constant, imputed
+    constant / all zero, both zero).  The reference holds the measured matrix in a float32 DataFrame and scales it
+    there, so its own values carry float32 noise (~1e-8; 2.7e-6 on the SSIM of the gene that is zero in both matrices,
+    where its fillna value 1e-20 is a float32 on one side and a float64 on the other): asserted to 1e-5 absolute; nan
+    where the reference has nan."""
+    from stdiff_amd.metrics import gene_metrics
+    g = np.load(os.path.join(golden_dir, "g9_metrics.npz"))
+    got = gene_metrics(torch.from_numpy(g["imputed"]).to(DEV), torch.from_numpy(g["raw"]).to(DEV))
+    for k in ("SSIM", "SPCC", "JS", "RMSE"):
+        ref = g[k]
+        assert np.array_equal(np.isnan(ref), np.isnan(got[k])), (k, ref, got[k])
+        ok = ~np.isnan(ref)
+        err = np.abs(got[k][ok] - ref[ok]).max()
+        print(f"G9 {k}: max |device - reference| = {err:.2e} over {ok.sum()} genes ({(~ok).sum()} nan in both)")
+        assert err < 1e-5, (k, got[k], ref)
+
+
+def test_scale_matches_reference_golden(golden_dir):
+    """SURVEY 8(f).4, the pinnable stage: golden G10 = the reference's `scale` (process/data.py:79-83) run on sklearn's
+    MaxAbsScaler; the device kernel (stdiff_preprocess_rows, target_sum = 0) is bit-equal, in place as well."""
+    from stdiff_amd.process.preprocess import scale
+    g = np.load(os.path.join(golden_dir, "g10_scale.npz"))
+    x = torch.from_numpy(g["X"]).to(DEV)
+    got = scale(x)
+    assert np.array_equal(got.cpu().numpy(), g["scaled"])
+    scale(x, out=x)
+    assert np.array_equal(x.cpu().numpy(), g["scaled"])
 
 
 @pytest.mark.parametrize("N", [1, 5, 1024, 1025, 4500])

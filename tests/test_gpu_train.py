@@ -276,6 +276,36 @@ def test_autograd_bridge_matches_oracle():
             assert relerr(prm.grad, leaves[n].grad) < 1e-4, n
 
 
+def test_autograd_two_forwards_before_backward():
+    """loss = f(model(x1,t,y1)) + f(model(x2,t,y2)); loss.backward(): the second forward of the same batch size must
+    not touch the first one's saved inputs / activations (each pending forward owns a buffer set)."""
+    G, H, depth, heads, C = 48, 128, 2, 4, 40
+    m, p = build(G, H, depth, heads, 22, "fp32")
+    m.train()
+    x1, y1, x2, y2 = rnd(C, G, seed=1), rnd(C, G, seed=2), rnd(C, G, seed=5), rnd(C, G, seed=6)
+    t1 = torch.randint(0, 1000, (C,), generator=torch.Generator().manual_seed(3))
+    t2 = torch.randint(0, 1000, (C,), generator=torch.Generator().manual_seed(7))
+    w1, w2 = rnd(C, G, seed=4), rnd(C, G, seed=8)
+    o1 = m(x1, t1, y1)
+    o2 = m(x2, t2, y2)
+    ((o1 * w1.to(DEV)).sum() + (o2 * w2.to(DEV)).sum()).backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items() if k != "condi_emb.weight"}
+    q = dict(p)
+    q.update(leaves)
+    r1 = O.dit_forward(q, x1, t1, y1, heads, depth)
+    r2 = O.dit_forward(q, x2, t2, y2, heads, depth)
+    ((r1 * w1).sum() + (r2 * w2).sum()).backward()
+    assert relerr(o1, r1) < 1e-5 and relerr(o2, r2) < 1e-5
+    for n, prm in m.named_parameters():
+        if n != "condi_emb.weight":
+            assert relerr(prm.grad, leaves[n].grad) < 1e-4, n
+    # and a third, single forward / backward afterwards reuses a free set
+    m.zero_grad()
+    o3 = m(x1, t1, y1)
+    (o3 * w1.to(DEV)).sum().backward()
+    assert relerr(o3, r1) < 1e-5
+
+
 def test_train_bf16_tracks_fp32(golden_dir):
     from stdiff_amd.train_engine import TrainEngine
     g = np.load(os.path.join(golden_dir, "g6_train.npz"))
@@ -419,6 +449,110 @@ def test_ddp_train_step_two_ranks_golden(golden_dir, backend):
         p_.join(60)
     for rank, status, info in res:
         assert status == "ok", f"rank {rank}: {info}"
+
+
+# ---------------------------------------------------------------- spot-sharded sampling, two ranks
+_SHARD_CFG = dict(N=7 * 48 + 20, G=64, H=128, depth=2, heads=4, B=48, T=8, seed=31, noise_seed=77)
+
+
+def _shard_inputs():
+    c = _SHARD_CFG
+    mk = O.kfold_mask(c["G"], 0)
+    gt = ((O.synth_expression(c["N"], c["G"], 5) * mk) * 2 - 1).astype(np.float32)
+    return mk, gt
+
+
+def _shard_worker(rank, world, port, q, backend):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = f"cuda:{rank}" if backend == "nccl" else "cuda:0"
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stdiff_amd import parallel as P
+        from stdiff_amd.model.stDiff_scheduler import NoiseScheduler
+        from stdiff_amd.process.data import get_data_loader
+        c = _SHARD_CFG
+        m, _ = build(c["G"], c["H"], c["depth"], c["heads"], c["seed"], "fp32")
+        m = m.to(dev)
+        mk, gt = _shard_inputs()
+        uploaded = []
+        real = P.loader_condition_rows
+
+        def spy(dl, lo, hi, device):
+            uploaded.append((lo, hi))
+            return real(dl, lo, hi, device)
+        P.loader_condition_rows = spy
+        dl = get_data_loader(gt, gt, batch_size=c["B"], is_shuffle=False)              # the reference's host loader
+        out = P.sample_stDiff_sharded(m, dl, NoiseScheduler(c["T"], beta_schedule="cosine"), mk, gt, num_step=c["T"],
+                                      sample_shape=gt.shape, sample_intermediate=c["T"], seed=c["noise_seed"])
+        lo, hi, local = P.sample_stDiff_sharded(m, dl, NoiseScheduler(c["T"], beta_schedule="cosine"), mk, gt,
+                                                num_step=c["T"], seed=c["noise_seed"], gather=False)
+        # the checksum the bench line carries, through the same object
+        ss = P.ShardedSampler(m, NoiseScheduler(c["T"], beta_schedule="cosine"), mk, P.loader_chunk_lens(dl),
+                              lambda a, b: (torch.from_numpy(gt[a:b]).to(dev), torch.from_numpy(gt[a:b]).to(dev)),
+                              seed=c["noise_seed"])
+        ss.init()
+        ss.run(list(range(c["T"]))[::-1])
+        digest, total = ss.checksum()
+        q.put((rank, "ok", dict(out=out, lo=lo, hi=hi, local=local, uploaded=uploaded, digest=digest, total=total)))
+    except Exception:                                        # noqa: BLE001 -- reported to the parent
+        import traceback
+        q.put((rank, "fail", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend", _ddp_backends())
+def test_sharded_sampling_two_ranks_equals_single_process(backend):
+    """sample_stDiff_sharded on two ranks (gloo: both on cuda:0; nccl where two GPUs are visible) == sample_stDiff in one
+    process, BIT FOR BIT: chunk-aligned shards, noise keyed by the global row, one device all_gather of padded shards.
+    Each rank uploads only ITS rows, and the cross-rank checksum of the bench line equals the single-process one."""
+    import socket
+    import torch.multiprocessing as mp
+    from stdiff_amd import parallel as P
+    from stdiff_amd.model.sample import sample_stDiff
+    from stdiff_amd.model.stDiff_scheduler import NoiseScheduler
+    from stdiff_amd.process.data import get_data_loader
+    c = _SHARD_CFG
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q, backend)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p_ in procs:
+        p_.join(60)
+    for rank, status, info in res:
+        assert status == "ok", f"rank {rank}: {info}"
+    m, _ = build(c["G"], c["H"], c["depth"], c["heads"], c["seed"], "fp32")
+    mk, gt = _shard_inputs()
+    dl = get_data_loader(gt, gt, batch_size=c["B"], is_shuffle=False)
+    ref = sample_stDiff(m, dl, NoiseScheduler(c["T"], beta_schedule="cosine"), mask=mk, gt=gt, device=DEV, num_step=c["T"],
+                        sample_shape=gt.shape, is_condi=True, sample_intermediate=c["T"], seed=c["noise_seed"],
+                        is_tqdm=False)
+    lens = P.loader_chunk_lens(dl)
+    assert lens == [48] * 7 + [20]
+    one = P.ShardedSampler(m, NoiseScheduler(c["T"], beta_schedule="cosine"), mk, lens,
+                           lambda a, b: (torch.from_numpy(gt[a:b]).to(DEV), torch.from_numpy(gt[a:b]).to(DEV)),
+                           seed=c["noise_seed"])
+    one.init()
+    one.run(list(range(c["T"]))[::-1])
+    digest1, total1 = one.checksum()
+    assert np.array_equal(one.x.cpu().numpy(), ref)
+    for rank, _, r in sorted(res):
+        lo, hi, _ = P.shard_chunks(lens, rank, 2)
+        assert (r["lo"], r["hi"]) == (lo, hi) and np.array_equal(r["local"], ref[lo:hi])
+        assert np.array_equal(r["out"], ref), rank                       # gathered result, every rank
+        assert set(r["uploaded"]) == {(lo, hi)}, r["uploaded"]            # only this rank's rows went to the GPU
+        assert r["digest"] == digest1 and abs(r["total"] - total1) <= 1e-9 * abs(total1)
 
 
 def test_rccl_bucket_path_on_one_rank(golden_dir, monkeypatch):

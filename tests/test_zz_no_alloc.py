@@ -43,12 +43,22 @@ def test_static_scratch_gemm_matches_workspace_gemm(dt):
             assert float((got - full).abs().max()) < (2e-2 if dt == "bf16" else 1e-4) * float(full.abs().max())
 
 
-def test_static_scratch_rejects_oversized_problems():
+def test_static_scratch_rejects_oversized_splits_only(gemm_knobs):
+    """Shapes that never split along K need no scratch and pass through whatever their size (round-2 advice: the
+    131072-row GEMMs of the sampler were rejected by a blanket size check); a shape that WOULD split but whose smallest
+    split (3 slices of the fp32 partial product) does not fit the 64 MiB array is rejected before anything is launched.
+    With the default knobs a splitting shape has at most CUs/3 tiles of 128 x 128 (17 MB for 3 slices), so the limit is
+    only reachable with a raised STDIFF_SPLITK_BLOCKS."""
     from stdiff_amd import ops
-    M, N, K = 4096, 4096, 64                      # 2 * M * N * 4 bytes = 128 MiB > 64 MiB
-    A = torch.zeros(M, K, device=DEV)
-    W = torch.zeros(N, K, device=DEV)
+    M, N, K = 4096, 4096, 1024                    # one slice of the partial product = 64 MiB
+    A = torch.randn(M, K, device=DEV)
+    W = torch.randn(N, K, device=DEV) * K ** -0.5
+    ref = ops.gemm(A, W, None, out=torch.empty(M, N, device=DEV))
     out = torch.zeros(M, N, device=DEV)
+    ops.gemm(A, W, None, out=out, static_scratch=True)        # 1024 tiles: no split, no scratch, no size limit
+    assert torch.equal(out, ref)
+    gemm_knobs(STDIFF_SPLITK_BLOCKS="100000")                 # now the host WANTS 16 slices of 64 MiB each
+    out.zero_()
     with pytest.raises(ValueError, match="static scratch"):
         ops.gemm(A, W, None, out=out, static_scratch=True)
     assert float(out.abs().max()) == 0.0            # nothing was launched

@@ -501,6 +501,97 @@ def g8():
     np.savez(os.path.join(OUT, "g8_driver.npz"), **out)
 
 
+# ---------------------------------------------------------------- G9: the evaluation block's per-gene metrics
+def _reference_metric_code():
+    """cal_ssim, scale_max, scale_z_score, scale_plus and CalculateMeteics of test-stDiff.py:203-364, EXECUTED from the
+    reference's own file: the script cannot be imported (scanpy, argparse and a full experiment at module level), so the
+    definitions are taken out of its syntax tree by name and compiled as they stand -- nothing is retyped here."""
+    import ast
+    import pandas as pd
+    import scipy.stats as st
+    path = os.path.join(REF, "test-stDiff.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    want = {"cal_ssim", "scale_max", "scale_z_score", "scale_plus", "CalculateMeteics"}
+    body = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in want]
+    assert {n.name for n in body} == want
+    ns = {"np": np, "pd": pd, "st": st}
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+def g9():
+    import tempfile
+    import warnings
+    import pandas as pd
+    print("G9 per-gene metrics: the reference's CalculateMeteics.SSIM / SPCC / JS / RMSE (test-stDiff.py:254-364)")
+    ns = _reference_metric_code()
+    rng = np.random.default_rng(9)
+    N, G = 300, 14
+    lam = rng.lognormal(-0.5, 1.0, size=G)
+    raw = rng.poisson(lam[None, :] * rng.lognormal(0.0, 0.5, size=(N, 1))).astype(np.float32)   # tie-heavy counts
+    # imputed: a noisy monotone function of the counts, on a 1/1024 grid (exact in fp32 AND as the decimal text of the
+    # CSV the reference reads the imputed matrix back from), mostly positive with exact zeros
+    imp = np.log1p(raw) * 0.7 + rng.normal(0, 0.25, size=(N, G))
+    imp = (np.round(np.clip(imp, 0, None) * 1024) / 1024).astype(np.float32)
+    # degenerate columns, as real panels have them (a gene nobody expresses; a saturated one)
+    raw[:, 9] = 0.0                      # measured gene all zero
+    raw[:, 10] = 3.0                     # measured gene constant
+    imp[:, 11] = 0.5                     # imputed gene constant
+    raw[:, 12] = 0.0
+    imp[:, 12] = 0.0                     # both all zero
+    imp[:, 13] = 0.0                     # imputed all zero, measured regular
+    genes = [f"Gene{j}" for j in range(G)]
+    with tempfile.TemporaryDirectory() as td:
+        csv = os.path.join(td, "diffusion_impute.csv")
+        pd.DataFrame(imp.astype(np.float64), columns=genes).to_csv(csv, header=1, index=1)        # :198-199
+        back = pd.read_csv(csv, header=0, index_col=0).to_numpy()
+        assert np.array_equal(back.astype(np.float32), imp) and np.array_equal(back, imp.astype(np.float64))
+        cm = ns["CalculateMeteics"](raw, genes, impute_count_file=csv, prefix=os.path.join(td, "x"), metric=None)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            with np.errstate(all="ignore"):
+                res = {"SSIM": cm.SSIM(cm.raw_count, cm.impute_count), "SPCC": cm.SPCC(cm.raw_count, cm.impute_count),
+                       "JS": cm.JS(cm.raw_count, cm.impute_count), "RMSE": cm.RMSE(cm.raw_count, cm.impute_count)}
+    out = dict(raw=raw, imputed=imp)
+    for k, df in res.items():
+        assert list(df.columns) == [g.upper() for g in genes]
+        out[k] = df.to_numpy(dtype=np.float64).reshape(G)
+        print(f"  {k}: " + " ".join(f"{v:.4g}" for v in out[k]))
+    np.savez(os.path.join(OUT, "g9_metrics.npz"), **out)
+
+
+# ---------------------------------------------------------------- G10: scale() of process/data.py (SURVEY 8f.4)
+def g10():
+    """process/data.py:79-83 `scale` imported from the reference (stubs for the absent anndata / scanpy packages only;
+    sklearn's MaxAbsScaler, which does the arithmetic, is the real one) and run on an object with `.X`.
+    normalize_total / log1p are scanpy's and stay unpinned."""
+    import importlib.util
+    print("G10 scale(): MaxAbsScaler().fit_transform(X.T).T of the reference's process/data.py")
+    for name in ("anndata", "scanpy"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.AnnData = object
+            sys.modules[name] = m
+    import scipy.sparse
+    if not hasattr(scipy.sparse, "csr"):
+        scipy.sparse.csr = types.ModuleType("scipy.sparse.csr")
+    spec = importlib.util.spec_from_file_location("ref_process_data", os.path.join(REF, "process", "data.py"))
+    ref_data = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_data)
+    rng = np.random.default_rng(10)
+    N, G = 257, 75
+    counts = rng.poisson(rng.lognormal(0, 1, size=(1, G)) * rng.lognormal(0, 0.5, size=(N, 1))).astype(np.float32)
+    X = np.log1p(counts / np.maximum(counts.sum(1, keepdims=True), 1) * 1e4).astype(np.float32)
+    X[5] = 0.0                                       # a cell without counts: divides by 1
+    X[6] *= -1.0                                     # max ABS value
+    X[7, 3] = -2.0 * X[7].max() - 1.0
+    obj = types.SimpleNamespace(X=X.copy())
+    got = ref_data.scale(obj).X
+    assert got.dtype == np.float32 and got.shape == X.shape
+    np.savez(os.path.join(OUT, "g10_scale.npz"), X=X, scaled=got)
+    print(f"  scaled: row max-abs in [{np.abs(got).max(1).min():.3f}, {np.abs(got).max(1).max():.3f}]")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -516,6 +607,10 @@ if __name__ == "__main__":
         g6_g7()
     if only in (None, "g8"):
         g8()
+    if only in (None, "g9"):
+        g9()
+    if only in (None, "g10"):
+        g10()
     print("goldens written to", OUT)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
