@@ -39,15 +39,16 @@ __device__ __forceinline__ f32x4 normal4(uint64_t seed, int64_t grow, uint32_t c
     philox4x32_10((uint32_t)grow, (uint32_t)((uint64_t)grow >> 32), cgroup, tag, (uint32_t)seed,
                   (uint32_t)(seed >> 32), r);
     f32x4 z;
+    // Box-Muller on the hardware transcendentals: v_log_f32 is log2, v_sin_f32 / v_cos_f32 take their argument in
+    // REVOLUTIONS (sin(2 pi u) = v_sin(u)), so no range reduction is needed for u in (0, 1).  ~1e-6 absolute error:
+    // noise quality, not parity (parity runs inject their noise); the libm calls were a third of the step kernel's time
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         float u1 = ((float)(r[2 * i] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
         float u2 = ((float)(r[2 * i + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-        float rad = sqrtf(-2.0f * logf(u1));
-        float s, c;
-        sincosf(6.283185307179586f * u2, &s, &c);
-        z[2 * i] = rad * c;
-        z[2 * i + 1] = rad * s;
+        float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));      // sqrt(-2 ln u1)
+        z[2 * i] = rad * __builtin_amdgcn_cosf(u2);
+        z[2 * i + 1] = rad * __builtin_amdgcn_sinf(u2);
     }
     return z;
 }
@@ -91,26 +92,46 @@ __global__ __launch_bounds__(256) void ddpm_step_kernel(stdiff_step_args a, int 
         const int c = cg * 4, n = min(4, a.G - c);
         const f32x4 m = load4<VEC>(a.mask + c, n);
         const bool known = !zb && m[0] == 1.0f && (n < 2 || m[1] == 1.0f) && (n < 3 || m[2] == 1.0f) && (n < 4 || m[3] == 1.0f);
-        for (int r = blockIdx.x * rpb + ty; r < a.R; r += gridDim.x * rpb) {
-            const size_t off = (size_t)r * a.G + c;
-            const f32x4 g = load4<VEC>(a.gt + off, n);
-            f32x4 o = g;
-            if (!known) {
-                const f32x4 x = load4<VEC>(a.x + off, n), e = load4<VEC>(a.eps + off, n);
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                if (t > 0) z = zb ? load4<VEC>(zb + off, n) : normal4(a.seed, a.row_offset + r, (uint32_t)cg, (uint32_t)t);
+        // 4 rows per pass, every load of the pass issued before the first use (memory-level parallelism per thread)
+        constexpr int U = 4;
+        const int rstep = gridDim.x * rpb;
+        for (int r0 = blockIdx.x * rpb + ty; r0 < a.R; r0 += U * rstep) {
+            f32x4 g[U], x[U], e[U], z[U];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float x0 = a.pred_type == 0
-                                   ? fminf(fmaxf(subf(mulf(ca, x[j]), mulf(cb, e[j])), -1.0f), 1.0f)
-                                   : e[j];
-                    float mu = addf(mulf(c1, x0), mulf(c2, x[j]));
-                    if (t > 0) mu = addf(mu, mulf(sg, z[j]));
-                    o[j] = splice(mu, m[j], g[j]);
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + u * rstep;
+                if (r < a.R) {
+                    const size_t off = (size_t)r * a.G + c;
+                    g[u] = load4<VEC>(a.gt + off, n);
+                    if (!known) {
+                        x[u] = load4<VEC>(a.x + off, n);
+                        e[u] = load4<VEC>(a.eps + off, n);
+                        if (t > 0 && zb) z[u] = load4<VEC>(zb + off, n);
+                    }
                 }
             }
-            store4<VEC>(a.x + off, o, n);
-            if (a.xp) store4p((TP*)a.xp + (size_t)r * a.ldxp + c, o, n, pvec);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + u * rstep;
+                if (r >= a.R) break;
+                const size_t off = (size_t)r * a.G + c;
+                f32x4 o = g[u];
+                if (!known) {
+                    f32x4 zz = {0.f, 0.f, 0.f, 0.f};
+                    if (t > 0) zz = zb ? z[u] : normal4(a.seed, a.row_offset + r, (uint32_t)cg, (uint32_t)t);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x0 = a.pred_type == 0
+                                       ? fminf(fmaxf(subf(mulf(ca, x[u][j]), mulf(cb, e[u][j])), -1.0f), 1.0f)
+                                       : e[u][j];
+                        float mu = addf(mulf(c1, x0), mulf(c2, x[u][j]));
+                        if (t > 0) mu = addf(mu, mulf(sg, zz[j]));
+                        o[j] = splice(mu, m[j], g[u][j]);
+                    }
+                }
+                store4<VEC>(a.x + off, o, n);
+                if (a.xp) store4p((TP*)a.xp + (size_t)r * a.ldxp + c, o, n, pvec);
+            }
         }
     }
 }

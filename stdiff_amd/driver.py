@@ -45,7 +45,7 @@ def fold_mask(gene_num, test_ind):
 def diffusion_impute(data_seq_array, data_spatial_array, *, lr=0.00016046744893538737, depth=6, num_epoch=900,
                      diffusion_step=1500, batch_size=512, hidden_size=1024, head=16, n_splits=5, rand=0,
                      device=torch.device('cuda:0'), save_dir=None, folds=None, compute_dtype=None, is_tqdm=False,
-                     device_loader=True, sample_seed=None, sample_noise=None):
+                     device_loader=True, sample_seed=None, sample_noise=None, _raw=False):
     """Returns (impu [cells, genes] in [0,1], with every gene imputed by the fold that held it out; columns of folds not
     in `folds` stay 0), like the reference's `impu`.  Defaults are the reference's (test-stDiff.py:27-34,64-70).
 
@@ -104,4 +104,31 @@ def diffusion_impute(data_seq_array, data_spatial_array, *, lr=0.000160467448935
                                    is_classifier_guidance=False, omega=0.2, is_tqdm=is_tqdm, seed=sample_seed,
                                    **inject)
         all_pred_res[:, test_ind] = imputation[:, test_ind]          # :181
+    if _raw:                      # [-1, 1] values of the folds that ran, zeros elsewhere (diffusion_impute_fold_parallel)
+        return all_pred_res
     return (all_pred_res + 1) / 2                                    # :184
+
+
+def diffusion_impute_fold_parallel(data_seq_array, data_spatial_array, *, group=None, n_splits=5, **kw):
+    """diffusion_impute with the gene folds spread over the ranks of `group` (the folds are independent --
+    each trains its own model on its own mask and imputes its own held-out genes, test-stDiff.py:79-182 -- so they are
+    a second, trivially parallel axis next to spot sharding).  Rank r runs folds r, r + W, ...; every rank passes the same
+    arrays and keyword arguments (`device` per rank).  The per-fold columns are merged with ONE all-reduce (each gene is
+    written by exactly one fold, every other rank holds zeros there), and every rank returns the full matrix in [0, 1].
+    Without a process group this is diffusion_impute.  Pass `sample_seed` for results that do not depend on the rank
+    count (the default seed is drawn per call from each rank's own generator)."""
+    from .parallel import _dist
+    dist, rank, world = _dist(group)
+    mine = [k for k in range(n_splits) if k % world == rank]
+    if kw.get("folds") is not None:
+        mine = [k for k in mine if k in kw["folds"]]
+    kw = dict(kw, folds=mine, n_splits=n_splits, _raw=True)
+    raw = diffusion_impute(data_seq_array, data_spatial_array, **kw)
+    if dist is not None and world > 1:
+        nccl = dist.get_backend(group) == "nccl"
+        t = torch.from_numpy(np.ascontiguousarray(raw))
+        if nccl:
+            t = t.to(kw.get("device", torch.device("cuda:0")))
+        dist.all_reduce(t, group=group)                 # x + 0 + ... + 0: exact, whatever the order
+        raw = t.cpu().numpy()
+    return (raw + 1) / 2

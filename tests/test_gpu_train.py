@@ -555,6 +555,72 @@ def test_sharded_sampling_two_ranks_equals_single_process(backend):
         assert r["digest"] == digest1 and abs(r["total"] - total1) <= 1e-9 * abs(total1)
 
 
+# ---------------------------------------------------------------- fold-parallel driver, two ranks
+def _fold_worker(rank, world, port, golden_dir, ckdir, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from stdiff_amd import driver
+        g = np.load(os.path.join(golden_dir, "g8_driver.npz"))
+        n_sc, n_st, G, H, depth, heads, B, T, num_epoch, n_splits, rand = [int(v) for v in g["cfg"]]
+        ran = []
+        real = driver.sample_stDiff
+
+        def spy(*a, **k):
+            ran.append(1)
+            return real(*a, **k)
+        driver.sample_stDiff = spy
+        impu = driver.diffusion_impute_fold_parallel(
+            g["seq"], g["st"], lr=float(g["lr"][0]), depth=depth, num_epoch=num_epoch, diffusion_step=T, batch_size=B,
+            hidden_size=H, head=heads, n_splits=n_splits, rand=rand, device=torch.device("cuda:0"), save_dir=ckdir,
+            sample_noise=lambda idx: (g[f"x_T{idx}"], g[f"z{idx}"]))
+        q.put((rank, "ok", dict(impu=impu, folds_run=len(ran))))
+    except Exception:                                        # noqa: BLE001 -- reported to the parent
+        import traceback
+        q.put((rank, "fail", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fold_parallel_driver_two_ranks(golden_dir, tmp_path):
+    """The five folds of golden G8 spread over two ranks (3 + 2 folds; both on cuda:0 over gloo), merged by one
+    all-reduce: every rank returns the reference's `impu` (<= 2e-5, as the single-process driver test) and the two
+    ranks' matrices are bit-equal to each other and to the single-process driver's."""
+    import socket
+    import torch.multiprocessing as mp
+    from stdiff_amd.driver import diffusion_impute
+    g = np.load(os.path.join(golden_dir, "g8_driver.npz"))
+    n_sc, n_st, G, H, depth, heads, B, T, num_epoch, n_splits, rand = [int(v) for v in g["cfg"]]
+    for idx in range(1, n_splits + 1):
+        sd = {k[len(f"sd{idx}/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"sd{idx}/")}
+        torch.save(sd, os.path.join(tmp_path, "stDiff%d.pt" % idx))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fold_worker, args=(r, 2, port, golden_dir, str(tmp_path), q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p_ in procs:
+        p_.join(60)
+    for rank, status, info in res:
+        assert status == "ok", f"rank {rank}: {info}"
+    one = diffusion_impute(g["seq"], g["st"], lr=float(g["lr"][0]), depth=depth, num_epoch=num_epoch, diffusion_step=T,
+                           batch_size=B, hidden_size=H, head=heads, n_splits=n_splits, rand=rand,
+                           device=torch.device(DEV), save_dir=str(tmp_path),
+                           sample_noise=lambda idx: (g[f"x_T{idx}"], g[f"z{idx}"]))
+    by_rank = {rank: info for rank, _, info in res}
+    assert by_rank[0]["folds_run"] == 3 and by_rank[1]["folds_run"] == 2
+    for rank in (0, 1):
+        assert np.array_equal(by_rank[rank]["impu"], one), rank
+        assert float(np.abs(by_rank[rank]["impu"] - g["impu"]).max()) < 2e-5
+
+
 def test_rccl_bucket_path_on_one_rank(golden_dir, monkeypatch):
     """The data-parallel step's RCCL branch (backend "nccl": every gradient bucket all-reduced asynchronously on RCCL's
     stream as the backward pass completes it, handles waited before the gradient norm) on the ONE GPU this pool's boxes
