@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define STDIFF_ABI_VERSION 8
+#define STDIFF_ABI_VERSION 9
 
 enum { STDIFF_F32 = 0, STDIFF_BF16 = 1 };
 
@@ -56,7 +56,11 @@ enum {
      * rounded to the 16-bit format first: what stdiff_gemm(EPI_BIAS) into a 16-bit buffer followed by
      * stdiff_ln_modulate gives (bit for bit when the statistics come from stdiff_row_stats), without writing shift /
      * scale or re-reading them.  16-bit operands, N % 256 == 0, 16-byte aligned rows. */
-    STDIFF_EPI_LN_MOD = 7
+    STDIFF_EPI_LN_MOD = 7,
+    /* backward of GELU fused into the GEMM that produces its upstream gradient (dX of mlp.fc2, training):
+     *   C = round(v) * gelu_erf'(u_pre[m,n]),  u_pre given through `gate` / `ldgate` in the operand dtype,
+     * v rounded to the output dtype first -- bit for bit what stdiff_gemm(EPI_BIAS) followed by stdiff_gelu_bwd gives. */
+    STDIFF_EPI_GELU_BWD = 8
 };
 
 int stdiff_abi_version(void);
@@ -235,6 +239,13 @@ int stdiff_masked_mse(const float* pred, const float* noise, const float* mask, 
 int stdiff_ln_modulate_bwd(const void* dy, int lddy, int dtype, const float* x, int ldx, const float* mean,
                            const float* rstd, const void* scale, int ldmod, float* dx, int lddx, int accumulate,
                            void* dshift, void* dscale, int lddmod, int R, int H, void* stream);
+/* The same followed by the gated-residual backward that comes next in the chain (x_next = x + gate * branch, DiTblock,
+ * stDiff_model.py:114,116; d x_next is the dx formed here): dbranch = dx * gate, dgate = dx * branch, in one launch --
+ * bit for bit what stdiff_ln_modulate_bwd + stdiff_gate_bwd produce. */
+int stdiff_ln_modulate_bwd_gate(const void* dy, int lddy, int dtype, const float* x, int ldx, const float* mean,
+                                const float* rstd, const void* scale, int ldmod, float* dx, int lddx, int accumulate,
+                                void* dshift, void* dscale, int lddmod, const void* gate, int ldgate, const void* branch,
+                                int ldbr, void* dbranch, int lddb, void* dgate, int lddg, int R, int H, void* stream);
 /* gated residual backward: dbranch = dh*gate (dtype), dgate = dh*branch (dtype) ; dh fp32 */
 int stdiff_gate_bwd(const float* dh, int lddh, const void* gate, int ldgate, const void* branch, int ldbr,
                     void* dbranch, int lddb, void* dgate, int lddg, int dtype, int R, int H, void* stream);

@@ -126,6 +126,8 @@ _SIGS = {
     "stdiff_masked_mse": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp]),
     "stdiff_attention_bwd": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "stdiff_ln_modulate_bwd": (i32, [vp, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, vp, vp, i32, i32, i32, vp]),
+    "stdiff_ln_modulate_bwd_gate": (i32, [vp, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, vp, vp, i32,
+                                          vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp]),
     "stdiff_gate_bwd": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, i32, vp]),
     "stdiff_gelu_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     "stdiff_silu_bwd": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp]),
@@ -163,7 +165,7 @@ def lib(fp16=False):
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.stdiff_abi_version() != 8:
+        if L.stdiff_abi_version() != 9:
             raise RuntimeError(f"{base} ABI version mismatch")
         if L.stdiff_h16_format() != int(bool(fp16)):
             raise RuntimeError(f"{base} was built with the wrong 16-bit operand format")

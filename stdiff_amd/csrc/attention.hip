@@ -328,12 +328,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* o, int ldo, co
 
 // A: dQ.  lane = query row; loops over key tiles.
 template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ qkv, int ldqkv,
-                                                          const T* __restrict__ dout, int lddo,
-                                                          const float* __restrict__ lse,
-                                                          const float* __restrict__ delta, T* __restrict__ dqkv,
-                                                          int lddqkv, const int32_t* __restrict__ cu_rows, int heads,
-                                                          float c_log2, float scale) {
+__device__ __forceinline__ void attn_bwd_dq_body(const int bx, const T* __restrict__ qkv, int ldqkv,
+                                                 const T* __restrict__ dout, int lddo,
+                                                 const float* __restrict__ lse,
+                                                 const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                 int lddqkv, const int32_t* __restrict__ cu_rows, int heads,
+                                                 float c_log2, float scale) {
     using C = ACfg<T, D>;
     __shared__ __attribute__((aligned(16))) unsigned char k_r[BKV * C::RSTR];
     __shared__ __attribute__((aligned(16))) unsigned char k_t[C::TWO_IMAGES ? BKV * C::TSTR : 16];
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
 
     const int chunk = blockIdx.z, hd = blockIdx.y;
     const int r0 = cu_rows[chunk], len = cu_rows[chunk + 1] - r0;
-    const int q0 = blockIdx.x * BQ;
+    const int q0 = bx * BQ;
     if (q0 >= len) return;
     const int H = heads * D;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -392,12 +392,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const T* __restrict__ 
 
 // B: dK, dV.  lane = key row; loops over query tiles.
 template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, int ldqkv,
-                                                           const T* __restrict__ dout, int lddo,
-                                                           const float* __restrict__ lse,
-                                                           const float* __restrict__ delta, T* __restrict__ dqkv,
-                                                           int lddqkv, const int32_t* __restrict__ cu_rows, int heads,
-                                                           float c_log2, float scale) {
+__device__ __forceinline__ void attn_bwd_dkv_body(const int bx, const T* __restrict__ qkv, int ldqkv,
+                                                  const T* __restrict__ dout, int lddo,
+                                                  const float* __restrict__ lse,
+                                                  const float* __restrict__ delta, T* __restrict__ dqkv,
+                                                  int lddqkv, const int32_t* __restrict__ cu_rows, int heads,
+                                                  float c_log2, float scale) {
     using C = ACfg<T, D>;
     __shared__ __attribute__((aligned(16))) unsigned char q_r[BKV * C::RSTR];
     __shared__ __attribute__((aligned(16))) unsigned char q_t[C::TWO_IMAGES ? BKV * C::TSTR : 16];
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const T* __restrict__
 
     const int chunk = blockIdx.z, hd = blockIdx.y;
     const int r0 = cu_rows[chunk], len = cu_rows[chunk + 1] - r0;
-    const int kbase0 = blockIdx.x * BQ;
+    const int kbase0 = bx * BQ;
     if (kbase0 >= len) return;
     const int H = heads * D;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -484,21 +484,33 @@ int launch_fwd(const void* qkv, int ldqkv, void* out, int ldo, float* lse, const
     return STDIFF_OK;
 }
 
+// dQ and dK/dV as ONE launch: blocks [0, gx) of grid.x run the dQ pass, blocks [gx, 2 gx) the dK/dV pass (both read q, k,
+// v, dO, lse, delta; they write disjoint column ranges of dqkv).  At a 512-cell training batch either pass alone is 64
+// workgroups on a 256-CU chip and 23-25 us of latency; side by side they cost one of the two.
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, int ldqkv, const T* __restrict__ dout,
+                                                       int lddo, const float* __restrict__ lse,
+                                                       const float* __restrict__ delta, T* __restrict__ dqkv, int lddqkv,
+                                                       const int32_t* __restrict__ cu_rows, int heads, float c_log2,
+                                                       float scale) {
+    const int gx = gridDim.x >> 1;
+    if ((int)blockIdx.x < gx)
+        attn_bwd_dq_body<T, D>(blockIdx.x, qkv, ldqkv, dout, lddo, lse, delta, dqkv, lddqkv, cu_rows, heads, c_log2, scale);
+    else
+        attn_bwd_dkv_body<T, D>(blockIdx.x - gx, qkv, ldqkv, dout, lddo, lse, delta, dqkv, lddqkv, cu_rows, heads, c_log2, scale);
+}
+
 template <typename T>
 int launch_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const void* dout, int lddo, const float* lse,
                float* delta, void* dqkv, int lddqkv, const int32_t* cu, int n_chunks, int maxc, int R, int heads, int d,
                hipStream_t st) {
     hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(cdiv((long)R * heads, 4)), dim3(256), 0, st, (const T*)out, ldo,
                        (const T*)dout, lddo, delta, R, heads, d);
-    dim3 grid(cdiv(maxc, BQ), heads, n_chunks), block(256);
+    dim3 grid(2 * cdiv(maxc, BQ), heads, n_chunks), block(256);
     const float scale = 1.0f / sqrtf((float)d), c = scale * 1.4426950408889634f;
 #define CASE(DD)                                                                                                  \
-    do {                                                                                                          \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, DD>), grid, block, 0, st, (const T*)qkv, ldqkv, (const T*)dout, \
-                           lddo, lse, delta, (T*)dqkv, lddqkv, cu, heads, c, scale);                              \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, DD>), grid, block, 0, st, (const T*)qkv, ldqkv, (const T*)dout, \
-                           lddo, lse, delta, (T*)dqkv, lddqkv, cu, heads, c, scale);                              \
-    } while (0)
+    hipLaunchKernelGGL((attn_bwd_kernel<T, DD>), grid, block, 0, st, (const T*)qkv, ldqkv, (const T*)dout, lddo, lse,  \
+                       delta, (T*)dqkv, lddqkv, cu, heads, c, scale)
     if (d == 32) CASE(32);
     else if (d == 64) CASE(64);
     else if (d == 128) CASE(128);

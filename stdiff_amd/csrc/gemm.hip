@@ -95,6 +95,14 @@ template <int EPI, bool FAST = false> __device__ __forceinline__ f32x4 epi_math(
         o = r + g * pre;
     } else if constexpr (EPI == STDIFF_EPI_ADD || EPI == STDIFF_EPI_ACCUM) {
         o = pre + r;
+    } else if constexpr (EPI == STDIFF_EPI_GELU_BWD) {      // g = the saved pre-activation; stdiff_gelu_bwd's expression
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = g[j];
+            const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+            const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+            o[j] = pre[j] * (cdf + x * pdf);
+        }
     } else {
         o = pre;
     }
@@ -104,7 +112,7 @@ template <int EPI, bool FAST = false> __device__ __forceinline__ f32x4 epi_math(
 // aligned side loads for one piece (row / column already clamped into range by the caller)
 template <int EPI, typename T>
 __device__ __forceinline__ void epi_load(const Params& p, int gm, int gn, f32x4& g, f32x4& r) {
-    if constexpr (EPI == STDIFF_EPI_GATE_RES) g = ld4((const T*)p.gate + (size_t)gm * p.ldgate + gn);
+    if constexpr (EPI == STDIFF_EPI_GATE_RES || EPI == STDIFF_EPI_GELU_BWD) g = ld4((const T*)p.gate + (size_t)gm * p.ldgate + gn);
     if constexpr (EPI == STDIFF_EPI_GATE_RES || EPI == STDIFF_EPI_ADD) r = *(const f32x4*)(p.res + (size_t)gm * p.ldres + gn);
     if constexpr (EPI == STDIFF_EPI_ACCUM) r = *(const f32x4*)((const float*)p.C + (size_t)gm * p.ldc + gn);
 }
@@ -113,6 +121,12 @@ template <int EPI, typename T>
 __device__ __forceinline__ void epi_store(const Params& p, int gm, int gn, f32x4 pre, f32x4 g, f32x4 r) {
     // bf16 outputs take the polynomial GELU here too: every bf16 kernel then produces the same bits for the same
     // row, whichever tile shape the host heuristic picks (chunk-, lane- and shard-invariance of the sampler)
+    if constexpr (EPI == STDIFF_EPI_GELU_BWD) {      // the unfused pair rounds the GEMM result to the output dtype first
+        if (p.c_bf16) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pre[j] = bf2f(f2bf(pre[j]));
+        }
+    }
     if (p.c_bf16) st4((bf16_t*)p.C + (size_t)gm * p.ldc + gn, epi_math<EPI, true>(pre, g, r));
     else *(f32x4*)((float*)p.C + (size_t)gm * p.ldc + gn) = epi_math<EPI, false>(pre, g, r);
     if (p.C2) st4((T*)p.C2 + (size_t)gm * p.ldc2 + gn, pre);       // v itself, in the operand dtype
@@ -137,6 +151,13 @@ __device__ __forceinline__ void epilogue4_slow(const Params& p, int gm, int gn, 
                 break;
             case STDIFF_EPI_ADD: o = pre + p.res[(size_t)gm * p.ldres + n]; break;
             case STDIFF_EPI_ACCUM: o = pre + ((const float*)p.C)[(size_t)gm * p.ldc + n]; break;
+            case STDIFF_EPI_GELU_BWD: {
+                const float x = Elem<T>::ld((const T*)p.gate + (size_t)gm * p.ldgate + n);
+                const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+                const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+                o = (p.c_bf16 ? bf2f(f2bf(pre)) : pre) * (cdf + x * pdf);
+                break;
+            }
             default: o = pre;
         }
         if (p.c_bf16) ((bf16_t*)p.C)[(size_t)gm * p.ldc + n] = f2bf(o);
@@ -153,6 +174,7 @@ __device__ __forceinline__ void epilogue4_slow(const Params& p, int gm, int gn, 
         case STDIFF_EPI_GATE_RES: CALL(STDIFF_EPI_GATE_RES); break; \
         case STDIFF_EPI_ADD: CALL(STDIFF_EPI_ADD); break;          \
         case STDIFF_EPI_ACCUM: CALL(STDIFF_EPI_ACCUM); break;      \
+        case STDIFF_EPI_GELU_BWD: CALL(STDIFF_EPI_GELU_BWD); break; \
         default: CALL(STDIFF_EPI_BIAS); break;                     \
     }
 
@@ -1649,7 +1671,7 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
     STDIFF_CHECK_ARG(a->A && a->W && a->C);
     STDIFF_CHECK_ARG(a->a_dtype == STDIFF_F32 || a->a_dtype == STDIFF_BF16);
     STDIFF_CHECK_ARG(a->c_dtype == STDIFF_F32 || a->c_dtype == STDIFF_BF16);
-    STDIFF_CHECK_ARG(a->epi >= STDIFF_EPI_BIAS && a->epi <= STDIFF_EPI_LN_MOD);
+    STDIFF_CHECK_ARG(a->epi >= STDIFF_EPI_BIAS && a->epi <= STDIFF_EPI_GELU_BWD);
     if (a->M == 0 || a->N == 0) return STDIFF_OK;
     const bool bf = a->a_dtype == STDIFF_BF16;
     const int bk = bf ? 64 : 16, epv = bf ? 8 : 4;
@@ -1666,6 +1688,7 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
         return STDIFF_ERR_ARG;
     if (a->epi == STDIFF_EPI_GATE_RES) STDIFF_CHECK_ARG(a->gate && a->res && a->c_dtype == STDIFF_F32);
     if (a->epi == STDIFF_EPI_ADD) STDIFF_CHECK_ARG(a->res != nullptr);
+    if (a->epi == STDIFF_EPI_GELU_BWD) STDIFF_CHECK_ARG(a->gate != nullptr && a->ldgate >= a->N && !a->C2);
     if (a->epi == STDIFF_EPI_ACCUM) STDIFF_CHECK_ARG(a->c_dtype == STDIFF_F32);
     if (a->epi == STDIFF_EPI_GELU_SAVE) STDIFF_CHECK_ARG(a->C2 != nullptr);
     if (a->C2) STDIFF_CHECK_ARG(a->ldc2 >= a->N);
@@ -1688,6 +1711,7 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
     bool vec = a->N % 8 == 0 && a->ldc % 4 == 0 && (p.c_bf16 ? al8(a->C) : al16(a->C)) && (!a->bias || al16(a->bias));
     if (a->epi == STDIFF_EPI_GATE_RES)
         vec = vec && a->ldgate % 4 == 0 && (bf ? al8(a->gate) : al16(a->gate)) && al16(a->res) && a->ldres % 4 == 0;
+    if (a->epi == STDIFF_EPI_GELU_BWD) vec = vec && a->ldgate % 4 == 0 && (bf ? al8(a->gate) : al16(a->gate));
     if (a->epi == STDIFF_EPI_ADD) vec = vec && al16(a->res) && a->ldres % 4 == 0;
     if (a->C2) vec = vec && a->ldc2 % 4 == 0 && (bf ? al8(a->C2) : al16(a->C2));
     p.vec = vec ? ((p.c_bf16 && a->ldc % 8 == 0 && al16(a->C)) ? 2 : 1) : 0;   // 2: bf16 C rows allow 16-byte stores
@@ -1727,6 +1751,7 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
     }
     p.k_valid = k_valid;
     if (ak || wk) tile = 1;                       // K-major staging exists in the 128 x 128 kernel only
+    if (a->epi == STDIFF_EPI_GELU_BWD) tile = 1;  // its rounding of v lives in the 128 x 128 kernel's epilogue (a training GEMM)
     if (t192) tile = 5;
     p.tiles_m = cdiv(a->M, tile == 1 ? BM : (tile == 5 ? 192 : 256));
     p.tiles_n = cdiv(a->N, tile == 1 ? BN : 256);

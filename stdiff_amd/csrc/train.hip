@@ -17,7 +17,9 @@ template <int NV, typename T>
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const T* dy, int lddy, const float* x, int ldx,
                                                          const float* mean, const float* rstd, const T* scale,
                                                          int ldmod, float* dx, int lddx, int accumulate, T* dshift,
-                                                         T* dscale, int lddmod, int R, int H) {
+                                                         T* dscale, int lddmod, int R, int H, const T* gate,
+                                                         int ldgate, const T* branch, int ldbr, T* dbranch, int lddb,
+                                                         T* dgate, int lddg) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= R) return;
@@ -59,6 +61,14 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const T* dy, int lddy, 
                 o += old;
             }
             *(f32x4*)dp = o;
+            // the gated residual that FOLLOWS in the backward chain (x_next = x + gate * branch, d x_next = the dx just
+            // formed): dbranch = dx * gate, dgate = dx * branch -- stdiff_gate_bwd's arithmetic on the value it would
+            // have re-read, without its launch
+            if (gate) {
+                const f32x4 gv = ld4(gate + (size_t)row * ldgate + c), bv = ld4(branch + (size_t)row * ldbr + c);
+                st4(dbranch + (size_t)row * lddb + c, o * gv);
+                st4(dgate + (size_t)row * lddg + c, o * bv);
+            }
         }
     }
 }
@@ -251,11 +261,13 @@ inline bool al8(const void* p) { return p == nullptr || ((uintptr_t)p & 7) == 0;
 template <typename T>
 int launch_ln_bwd(const void* dy, int lddy, const float* x, int ldx, const float* mean, const float* rstd,
                   const void* scale, int ldmod, float* dx, int lddx, int acc, void* dshift, void* dscale, int lddmod,
-                  int R, int H, hipStream_t st) {
+                  int R, int H, hipStream_t st, const void* gate = nullptr, int ldgate = 0, const void* branch = nullptr,
+                  int ldbr = 0, void* dbranch = nullptr, int lddb = 0, void* dgate = nullptr, int lddg = 0) {
     dim3 grid(cdiv(R, 4)), block(256);
 #define CASE(NV)                                                                                                   \
     hipLaunchKernelGGL((ln_mod_bwd_kernel<NV, T>), grid, block, 0, st, (const T*)dy, lddy, x, ldx, mean, rstd,     \
-                       (const T*)scale, ldmod, dx, lddx, acc, (T*)dshift, (T*)dscale, lddmod, R, H)
+                       (const T*)scale, ldmod, dx, lddx, acc, (T*)dshift, (T*)dscale, lddmod, R, H, (const T*)gate,   \
+                       ldgate, (const T*)branch, ldbr, (T*)dbranch, lddb, (T*)dgate, lddg)
     if (H <= 256) CASE(1);
     else if (H <= 512) CASE(2);
     else if (H <= 1024) CASE(4);
@@ -285,6 +297,30 @@ extern "C" int stdiff_ln_modulate_bwd(const void* dy, int lddy, int dtype, const
                                      lddmod, R, H, (hipStream_t)stream);
     return launch_ln_bwd<float>(dy, lddy, x, ldx, mean, rstd, scale, ldmod, dx, lddx, accumulate, dshift, dscale,
                                 lddmod, R, H, (hipStream_t)stream);
+}
+
+extern "C" int stdiff_ln_modulate_bwd_gate(const void* dy, int lddy, int dtype, const float* x, int ldx,
+                                           const float* mean, const float* rstd, const void* scale, int ldmod, float* dx,
+                                           int lddx, int accumulate, void* dshift, void* dscale, int lddmod,
+                                           const void* gate, int ldgate, const void* branch, int ldbr, void* dbranch,
+                                           int lddb, void* dgate, int lddg, int R, int H, void* stream) {
+    STDIFF_CHECK_ARG(dy && x && mean && rstd && scale && dx && dshift && dscale && R >= 0 && H > 0);
+    STDIFF_CHECK_ARG(gate && branch && dbranch && dgate);
+    STDIFF_CHECK_ARG(dtype == STDIFF_F32 || dtype == STDIFF_BF16);
+    if (R == 0) return STDIFF_OK;
+    if (H % 4) return STDIFF_ERR_SHAPE;
+    if (lddy % 4 || ldx % 4 || ldmod % 4 || lddx % 4 || lddmod % 4 || !al16(x) || !al16(dx) || !al8(dy) || !al8(scale) ||
+        !al8(dshift) || !al8(dscale) || ldgate % 4 || ldbr % 4 || lddb % 4 || lddg % 4 || !al8(gate) || !al8(branch) ||
+        !al8(dbranch) || !al8(dgate))
+        return STDIFF_ERR_ALIGN;
+    if (dtype == STDIFF_F32 && (!al16(dy) || !al16(scale) || !al16(dshift) || !al16(dscale) || !al16(gate) ||
+                                !al16(branch) || !al16(dbranch) || !al16(dgate)))
+        return STDIFF_ERR_ALIGN;
+    if (dtype == STDIFF_BF16)
+        return launch_ln_bwd<bf16_t>(dy, lddy, x, ldx, mean, rstd, scale, ldmod, dx, lddx, accumulate, dshift, dscale,
+                                     lddmod, R, H, (hipStream_t)stream, gate, ldgate, branch, ldbr, dbranch, lddb, dgate, lddg);
+    return launch_ln_bwd<float>(dy, lddy, x, ldx, mean, rstd, scale, ldmod, dx, lddx, accumulate, dshift, dscale,
+                                lddmod, R, H, (hipStream_t)stream, gate, ldgate, branch, ldbr, dbranch, lddb, dgate, lddg);
 }
 
 extern "C" int stdiff_gate_bwd(const float* dh, int lddh, const void* gate, int ldgate, const void* branch, int ldbr,

@@ -76,8 +76,9 @@ struct Ctx {
     }
     // out[M, n_in] (+)= dY[M, k_pad] W, W = [k_valid rows (out features)][n_in] read K-major
     int dX(bool on_side, int M, const void* dY, int lddy, int k_pad, const stdiff_train_linear& l, int k_valid, int n_in,
-           void* out, int ldo, int odt, int epi = STDIFF_EPI_BIAS) const {
+           void* out, int ldo, int odt, int epi = STDIFF_EPI_BIAS, const void* side_in = nullptr, int ldside = 0) const {
         stdiff_gemm_args g = {};
+        g.gate = side_in; g.ldgate = ldside;
         g.M = M; g.N = n_in; g.K = k_pad; g.A = dY; g.lda = lddy; g.a_dtype = w->dtype; g.W = l.w; g.ldw = n_in;
         g.C = out; g.ldc = ldo; g.c_dtype = odt; g.epi = epi; g.w_layout = STDIFF_K_MAJOR; g.k_valid = k_valid;
         g.workspace = ws(on_side); g.workspace_bytes = ws_bytes(on_side);
@@ -234,8 +235,18 @@ extern "C" int stdiff_dit_backward(const stdiff_train_weights* w, const stdiff_t
     // ---- final layer (FinalLayer.forward, stDiff_model.py:135-141)
     TRY(c.dW(w->out, G, H, a->deps, Gp, Gp, a->xnf, H, H));
     TRY(c.dX(false, C, a->deps, Gp, Gp, w->out, G, H, a->dxn, H, dt));
-    TRY(stdiff_ln_modulate_bwd(a->dxn, H, dt, a->h_last, H, a->meanf, a->rstdf, col(a->fmod, dt, H), 2 * H, a->dh, H, 0,
-                               col(a->dfmod, dt, 0), col(a->dfmod, dt, H), 2 * H, C, H, stream));
+    // every LayerNorm backward of the chain is followed by the gated-residual backward of the branch below it: one launch
+    // (stdiff_ln_modulate_bwd_gate).  Here: the MLP branch of the last block, h_D = hmid + gate_mlp * pm (:116)
+    if (D > 0) {
+        const stdiff_train_block_acts& sl = a->blocks[D - 1];
+        void* dml = a->dmod[(D - 1) & 1];
+        TRY(stdiff_ln_modulate_bwd_gate(a->dxn, H, dt, a->h_last, H, a->meanf, a->rstdf, col(a->fmod, dt, H), 2 * H, a->dh,
+                                        H, 0, col(a->dfmod, dt, 0), col(a->dfmod, dt, H), 2 * H, col(sl.mod, dt, 5 * H),
+                                        6 * H, sl.pm, H, a->dbr, H, col(dml, dt, 5 * H), 6 * H, C, H, stream));
+    } else {
+        TRY(stdiff_ln_modulate_bwd(a->dxn, H, dt, a->h_last, H, a->meanf, a->rstdf, col(a->fmod, dt, H), 2 * H, a->dh, H,
+                                   0, col(a->dfmod, dt, 0), col(a->dfmod, dt, H), 2 * H, C, H, stream));
+    }
     // d loss / d s accumulates over all adaLN projections and is needed only after the last block: its GEMMs ride with
     // the adaLN weight-gradient jobs (same dY), in issue order on whichever stream runs them
     TRY(c.dW(w->fada, 2 * H, H, a->dfmod, 2 * H, 2 * H, a->s, H, H, [&](bool sd) {
@@ -249,27 +260,33 @@ extern "C" int stdiff_dit_backward(const stdiff_train_weights* w, const stdiff_t
         const stdiff_train_block& b = w->blocks[k];
         const stdiff_train_block_acts& s = a->blocks[k];
         void* dmod = a->dmod[k & 1];
-        // MLP branch: h_{k+1} = hmid + gate_mlp * pm   (DiTblock.forward, stDiff_model.py:116)
-        TRY(stdiff_gate_bwd(a->dh, H, col(s.mod, dt, 5 * H), 6 * H, s.pm, H, a->dbr, H, col(dmod, dt, 5 * H), 6 * H, dt, C,
-                            H, stream));
+        // MLP branch: h_{k+1} = hmid + gate_mlp * pm   (DiTblock.forward, stDiff_model.py:116): dbr = dh * gate_mlp and
+        // d gate_mlp were written by the LayerNorm backward above this block (fused launch)
         TRY(c.dW(b.fc2, H, 4 * H, a->dbr, H, H, s.u, 4 * H, 4 * H));
-        TRY(c.dX(false, C, a->dbr, H, H, b.fc2, H, 4 * H, a->du, 4 * H, dt));
-        TRY(stdiff_gelu_bwd(a->du, s.upre, a->dupre, 4 * H, dt, C, 4 * H, stream));
+        // d(fc2 input) with the GELU backward in the GEMM's epilogue: dupre = (dbr W_fc2) * gelu'(upre)
+        TRY(c.dX(false, C, a->dbr, H, H, b.fc2, H, 4 * H, a->dupre, 4 * H, dt, STDIFF_EPI_GELU_BWD, s.upre, 4 * H));
         TRY(c.dW(b.fc1, 4 * H, H, a->dupre, 4 * H, 4 * H, s.xn2, H, H));
         TRY(c.dX(false, C, a->dupre, 4 * H, 4 * H, b.fc1, 4 * H, H, a->dxn, H, dt));
-        TRY(stdiff_ln_modulate_bwd(a->dxn, H, dt, s.hmid, H, s.mean2, s.rstd2, col(s.mod, dt, 4 * H), 6 * H, a->dh, H, 1,
-                                   col(dmod, dt, 3 * H), col(dmod, dt, 4 * H), 6 * H, C, H, stream));
-        // attention branch: hmid = h_k + gate_msa * pa   (:114)
-        TRY(stdiff_gate_bwd(a->dh, H, col(s.mod, dt, 2 * H), 6 * H, s.pa, H, a->dbr, H, col(dmod, dt, 2 * H), 6 * H, dt, C,
-                            H, stream));
+        // LayerNorm 2 backward + the attention branch's gate: hmid = h_k + gate_msa * pa   (:114)
+        TRY(stdiff_ln_modulate_bwd_gate(a->dxn, H, dt, s.hmid, H, s.mean2, s.rstd2, col(s.mod, dt, 4 * H), 6 * H, a->dh, H, 1,
+                                        col(dmod, dt, 3 * H), col(dmod, dt, 4 * H), 6 * H, col(s.mod, dt, 2 * H), 6 * H, s.pa,
+                                        H, a->dbr, H, col(dmod, dt, 2 * H), 6 * H, C, H, stream));
         TRY(c.dW(b.proj, H, H, a->dbr, H, H, s.o, H, H));
         TRY(c.dX(false, C, a->dbr, H, H, b.proj, H, H, a->do_, H, dt));
         TRY(stdiff_attention_bwd(s.qkv, 3 * H, s.o, H, a->do_, H, s.lse, a->delta, a->dqkv, 3 * H, a->cu_rows, 1, C, C,
                                  w->heads, d, dt, stream));
         TRY(c.dW(b.qkv, 3 * H, H, a->dqkv, 3 * H, 3 * H, s.xn1, H, H));
         TRY(c.dX(false, C, a->dqkv, 3 * H, 3 * H, b.qkv, 3 * H, H, a->dxn, H, dt));
-        TRY(stdiff_ln_modulate_bwd(a->dxn, H, dt, s.h, H, s.mean1, s.rstd1, col(s.mod, dt, H), 6 * H, a->dh, H, 1,
-                                   col(dmod, dt, 0), col(dmod, dt, H), 6 * H, C, H, stream));
+        if (k > 0) {        // LayerNorm 1 backward + the MLP gate of the block below (its dmod buffer is the other one)
+            const stdiff_train_block_acts& sb = a->blocks[k - 1];
+            void* dmb = a->dmod[(k - 1) & 1];
+            TRY(stdiff_ln_modulate_bwd_gate(a->dxn, H, dt, s.h, H, s.mean1, s.rstd1, col(s.mod, dt, H), 6 * H, a->dh, H, 1,
+                                            col(dmod, dt, 0), col(dmod, dt, H), 6 * H, col(sb.mod, dt, 5 * H), 6 * H, sb.pm,
+                                            H, a->dbr, H, col(dmb, dt, 5 * H), 6 * H, C, H, stream));
+        } else {
+            TRY(stdiff_ln_modulate_bwd(a->dxn, H, dt, s.h, H, s.mean1, s.rstd1, col(s.mod, dt, H), 6 * H, a->dh, H, 1,
+                                       col(dmod, dt, 0), col(dmod, dt, H), 6 * H, C, H, stream));
+        }
         TRY(c.dW(b.ada, 6 * H, H, dmod, 6 * H, 6 * H, a->s, H, H, [&](bool sd) {
             return c.dX(sd, C, dmod, 6 * H, 6 * H, b.ada, 6 * H, H, a->ds32, H, STDIFF_F32, STDIFF_EPI_ACCUM);
         }));
