@@ -136,6 +136,9 @@ int main(int argc, char** argv) {
     a.dmod[0] = f((size_t)C * 6 * H); a.dmod[1] = f((size_t)C * 6 * H); a.dfmod = f((size_t)C * 2 * H);
     a.dbr = f((size_t)C * H); a.du = f((size_t)C * 4 * H); a.dupre = f((size_t)C * 4 * H); a.do_ = f((size_t)C * H);
     a.dqkv = f((size_t)C * 3 * H); a.delta = (float*)f((size_t)C * heads); a.ds32 = (float*)f((size_t)C * H);
+    // second set of per-block dY scratch: one grouped weight-gradient launch per block (include/stdiff_hip.h)
+    for (int i = 0; i < 3; ++i) a.dbr_b[i] = f((size_t)C * H);
+    a.dqkv_b = f((size_t)C * 3 * H);
     a.dc = (float*)f((size_t)C * H); a.dcT = f((size_t)C * H); a.de1 = f((size_t)C * H); a.da1 = f((size_t)C * H);
     a.dhT = f((size_t)C * H);
     const int Cp = (C + 63) / 64 * 64, trows = Gp > H ? Gp : H;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define STDIFF_ABI_VERSION 9
+#define STDIFF_ABI_VERSION 10
 
 enum { STDIFF_F32 = 0, STDIFF_BF16 = 1 };
 
@@ -341,6 +341,26 @@ typedef struct {
 int stdiff_dit_forward(const stdiff_dit_weights* w, const stdiff_dit_workspace* ws, const void* xp, const void* s,
                        float* eps, int ldeps, void* stream);
 
+/* ---------------------------------------------------------------- grouped weight gradients
+ * The weight and bias gradients of up to 8 linear layers over ONE batch of C cells in one launch (what
+ * loss.backward() leaves in .grad of each nn.Linear, stDiff_train.py:77):  gw_i[M_i, N_i] = dY_i[:, :M_i]^T X_i[:, :N_i],
+ * gb_i[M_i] = column sums of dY_i (NULL: not wanted).  dY_i [C, >= M_i] and X_i [C, >= N_i] are read as they lie
+ * (row = cell); gradients are fp32 and OVERWRITTEN.  The K axis (cells) is never split: results do not depend on the
+ * number of CUs.  M_i % 8 (fp32: % 4), N_i % 8, 16-byte aligned rows; else STDIFF_ERR_SHAPE / STDIFF_ERR_ALIGN. */
+#define STDIFF_DW_GROUP_MAX 8
+typedef struct {
+    int M, N;
+    const void* dY; int lddy;
+    const void* X; int ldx;
+    float* gw; int ldgw;
+    float* gb;
+} stdiff_dw_problem;
+typedef struct {
+    int n, C, dtype;                    /* problems, cells, operand dtype (STDIFF_F32 / STDIFF_BF16) */
+    stdiff_dw_problem p[STDIFF_DW_GROUP_MAX];
+} stdiff_dw_group_args;
+int stdiff_dw_group(const stdiff_dw_group_args* g, void* stream);
+
 /* ---------------------------------------------------------------- whole-denoiser training pass
  * The forward of stDiff_train.py:72 (DiT_stDiff.forward, stDiff_model.py:231-243, on one mini-batch = one attention
  * chunk) keeping what the backward needs, and the backward of :77 (loss.backward() through the denoiser), each as ONE
@@ -386,6 +406,11 @@ typedef struct {
     void* tr[2][2];        /* G % 8 != 0 only: [stream: main, side][dY^T, X^T] transposed copies [max(Gp,H), round_up(C,64)] */
     void* splitk_ws; long long splitk_bytes;             /* split-K scratch of the launches on `stream` (may be NULL) */
     void* splitk_ws_side; long long splitk_side_bytes;   /* ... of the launches on the side stream */
+    /* Optional, all four or none: three more [C,H] and one more [C,3H] scratch.  With them the backward issues ONE
+     * stdiff_dw_group launch per DiT block (its five weight and bias gradients) instead of five jobs of three launches:
+     * the dY operands of a block (dbr of either branch, dupre with `du` as its twin, dqkv, dmod) then alternate between
+     * two sets so that a block's group can run while the chain is already in the next block. */
+    void* dbr_b[3]; void* dqkv_b;
 } stdiff_train_acts;
 /* side_stream (NULL = none): the adaLN projections of the forward and the weight-gradient jobs of the backward are
  * issued there and joined with events the library creates once per device (hipEventDisableTiming; no device memory):

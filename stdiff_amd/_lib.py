@@ -9,7 +9,7 @@ import os
 import torch
 
 F32, BF16, F16 = 0, 1, 2         # F16 exists on the Python side only: it selects the fp16 build, whose C code is 1
-EPI_BIAS, EPI_SILU, EPI_GELU, EPI_GATE_RES, EPI_ADD, EPI_GELU_SAVE, EPI_ACCUM, EPI_LN_MOD = range(8)
+EPI_BIAS, EPI_SILU, EPI_GELU, EPI_GATE_RES, EPI_ADD, EPI_GELU_SAVE, EPI_ACCUM, EPI_LN_MOD, EPI_GELU_BWD = range(9)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libstdiff_hip.so")
@@ -86,7 +86,16 @@ class TrainActs(C.Structure):
                [(n, vp) for n in ("dfmod", "dbr", "du", "dupre", "do_", "dqkv", "delta", "ds32", "dc", "dcT", "de1",
                                   "da1", "dhT")] + \
                [("tr", (vp * 2) * 2), ("splitk_ws", vp), ("splitk_bytes", C.c_longlong),
-                ("splitk_ws_side", vp), ("splitk_side_bytes", C.c_longlong)]
+                ("splitk_ws_side", vp), ("splitk_side_bytes", C.c_longlong), ("dbr_b", vp * 3), ("dqkv_b", vp)]
+
+
+class DwProblem(C.Structure):
+    _fields_ = [("M", i32), ("N", i32), ("dY", vp), ("lddy", i32), ("X", vp), ("ldx", i32), ("gw", vp), ("ldgw", i32),
+                ("gb", vp)]
+
+
+class DwGroupArgs(C.Structure):
+    _fields_ = [("n", i32), ("C", i32), ("dtype", i32), ("p", DwProblem * 8)]
 
 
 BucketFn = C.CFUNCTYPE(None, i32, vp)
@@ -106,6 +115,7 @@ _SIGS = {
     "stdiff_reload_env": (None, []),
     "stdiff_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "stdiff_gemm_static_scratch": (i32, [C.POINTER(GemmArgs), vp]),
+    "stdiff_dw_group": (i32, [C.POINTER(DwGroupArgs), vp]),
     "stdiff_transpose": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "stdiff_attention_fwd": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "stdiff_ln_modulate": (i32, [vp, i32, vp, vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, vp]),
@@ -165,7 +175,7 @@ def lib(fp16=False):
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.stdiff_abi_version() != 9:
+        if L.stdiff_abi_version() != 10:
             raise RuntimeError(f"{base} ABI version mismatch")
         if L.stdiff_h16_format() != int(bool(fp16)):
             raise RuntimeError(f"{base} was built with the wrong 16-bit operand format")

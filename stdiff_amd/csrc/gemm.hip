@@ -65,6 +65,7 @@ struct Params {
     int t_full, units;
     const float* ln_parts; int ln_nparts;         // STDIFF_EPI_LN_MOD: partial row moments of `res` [M][parts][2]
     float* stats_out;                             // gate-residual epilogue: partial row moments of C [M][tiles_n][2]
+    float* colsum;                                // gemm_dw_group_kernel only: sum over k of A[m][k]  (fp32 [M])
 };
 
 __device__ __forceinline__ void tile_of(int bid, int nblk, int tiles_m, int tiles_n, int& tm, int& tn) {
@@ -215,21 +216,28 @@ __device__ __forceinline__ void epi_rows128(const Params& p, const float* cl, in
 // the row) and the MFMA fragments come from ds_read_b64_tr_b16 (bf16: the hardware transposes a 4-row x 16-column
 // block per 16 lanes) or scalar LDS reads (fp32).  Rows k >= k_valid are staged as zeros (a batch that is not a
 // multiple of the K-slab).
-template <typename T, bool AK, bool WK>
-__global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
+// DEPTH: K-slabs of global loads kept in flight in registers (1 = the slab after the one being multiplied).  Grids of
+// at most one block per CU (the training step's batch-sized GEMMs) have nothing else on the CU to hide the load
+// latency behind, so they run with DEPTH = 3: a slab's loads are issued three multiplies before its LDS store.
+template <typename T> constexpr int smem128() {
+    constexpr int stage = 4 * BM * Cfg<T>::ROWB, cbytes = BM * CLD * 4;      // 2 buffers x (A + W)  |  the fp32 C image
+    return stage > cbytes ? stage : cbytes;
+}
+
+// GROUPED: the body runs as one problem of gemm_dw_group_kernel -- plain fp32 store only, and the tiles of the first
+// tile column also sum their A tile over k (p.colsum: the bias gradient of a weight-gradient product, on the matrix
+// cores: one more MFMA per row block against a fragment of ones).
+template <typename T, bool AK, bool WK, int DEPTH, bool GROUPED>
+__device__ __forceinline__ void gemm_nt_body(const Params& p, const int bid, unsigned char* smem) {
     using C = Cfg<T>;
     constexpr int BK = C::BK, EPV = C::EPV, NSLOT = C::NSLOT, ROWB = C::ROWB;
     constexpr int TILEB = BM * ROWB;               // bytes of one operand tile
     constexpr int LPT = BM * NSLOT / NT;           // 16-byte loads per thread per operand
-    constexpr int STAGE = 4 * TILEB;               // 2 buffers x (A + W)
-    constexpr int CBYTES = BM * CLD * 4;
-    constexpr int SMEM = STAGE > CBYTES ? STAGE : CBYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
     int tm, tn;
     const int ntiles = p.tiles_m * p.tiles_n;
-    const int split = blockIdx.x / ntiles;
-    tile_of(blockIdx.x - split * ntiles, ntiles, p.tiles_m, p.tiles_n, tm, tn);
+    const int split = bid / ntiles;
+    tile_of(bid - split * ntiles, ntiles, p.tiles_m, p.tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
@@ -268,31 +276,31 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
             soffw[i] = row * ROWB + ((slot ^ C::swz(row)) << 4);
         }
     }
-    u32x4 ra[LPT], rw[LPT];
-    auto gload = [&](int k0) {
+    u32x4 ra[DEPTH][LPT], rw[DEPTH][LPT];
+    auto gload = [&](int set, int k0) {          // `set` is a compile-time constant at every call site
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const int krow = (tid + NT * i) / PPR;
             if constexpr (AK) {
-                ra[i] = u32x4{0u, 0u, 0u, 0u};
-                if (cva[i] && k0 + krow < p.k_valid) ra[i] = *(const u32x4*)(ga[i] + (size_t)k0 * p.lda);
+                ra[set][i] = u32x4{0u, 0u, 0u, 0u};
+                if (cva[i] && k0 + krow < p.k_valid) ra[set][i] = *(const u32x4*)(ga[i] + (size_t)k0 * p.lda);
             } else {
-                ra[i] = *(const u32x4*)(ga[i] + k0);
+                ra[set][i] = *(const u32x4*)(ga[i] + k0);
             }
             if constexpr (WK) {
-                rw[i] = u32x4{0u, 0u, 0u, 0u};
-                if (cvw[i] && k0 + krow < p.k_valid) rw[i] = *(const u32x4*)(gw[i] + (size_t)k0 * p.ldw);
+                rw[set][i] = u32x4{0u, 0u, 0u, 0u};
+                if (cvw[i] && k0 + krow < p.k_valid) rw[set][i] = *(const u32x4*)(gw[i] + (size_t)k0 * p.ldw);
             } else {
-                rw[i] = *(const u32x4*)(gw[i] + k0);
+                rw[set][i] = *(const u32x4*)(gw[i] + k0);
             }
         }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int set, int buf) {
         unsigned char* b = smem + buf * 2 * TILEB;
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            *(u32x4*)(b + soffa[i]) = ra[i];
-            *(u32x4*)(b + TILEB + soffw[i]) = rw[i];
+            *(u32x4*)(b + soffa[i]) = ra[set][i];
+            *(u32x4*)(b + TILEB + soffw[i]) = rw[set][i];
         }
     };
 
@@ -303,6 +311,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4;
+    f32x4 accb[4];                                 // GROUPED: sum over k of this wave's A rows (every element the same sum)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool colsum = GROUPED && p.colsum != nullptr && tn == 0 && wn == 0;
     auto compute = [&](int buf) {
         const unsigned char* ba = smem + buf * 2 * TILEB;
         const unsigned char* bw = ba + TILEB;
@@ -339,6 +351,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
                         acc[mt][nt] = STDIFF_MFMA_16x16x32_H16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+                if constexpr (GROUPED) {
+                    if (colsum) {
+                        const h16 one = (h16)1.0f;
+                        const bf16x8 ones = {one, one, one, one, one, one, one, one};
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) accb[mt] = STDIFF_MFMA_16x16x32_H16(ones, af[mt], accb[mt], 0, 0, 0);
+                    }
+                }
             }
         } else {
             f32x4 af[4], wf[4];
@@ -367,18 +387,56 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nt][kk], af[mt][kk], acc[mt][nt], 0, 0, 0);
+            if constexpr (GROUPED) {
+                if (colsum) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            accb[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, af[mt][kk], accb[mt], 0, 0, 0);
+                }
+            }
         }
     };
 
     const int kb = split * p.nk_per, nk = min(p.K / BK - kb, p.nk_per);     // this block's K-slabs
-    gload(kb * BK);
-    sstore(0);
-    __syncthreads();
-    for (int k = 0; k < nk; ++k) {
-        if (k + 1 < nk) gload((kb + k + 1) * BK);
-        compute(k & 1);
-        if (k + 1 < nk) sstore((k + 1) & 1);
+    if constexpr (DEPTH == 1) {
+        gload(0, kb * BK);
+        sstore(0, 0);
         __syncthreads();
+        for (int k = 0; k < nk; ++k) {
+            if (k + 1 < nk) gload(0, (kb + k + 1) * BK);
+            compute(k & 1);
+            if (k + 1 < nk) sstore(0, (k + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        // Register set j % DEPTH carries slab j.  Every load and store below is unconditional (slab indices clamped to
+        // the last one: a few reloads at the tail whose LDS copies nobody reads) so that the compiler's counted waits
+        // see one straight-line load stream: the store of slab j + 1 waits with (DEPTH - 1) slabs still in flight.
+        const int last = kb + nk - 1;
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) gload(d, min(kb + d, last) * BK);
+        sstore(0, 0);
+        __syncthreads();
+        int j = 0;
+        for (; j + DEPTH <= nk; j += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                gload(d, min(kb + j + d + DEPTH, last) * BK);
+                compute((j + d) & 1);
+                sstore((d + 1) % DEPTH, (j + d + 1) & 1);
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH - 1; ++d) {
+            if (j + d < nk) {
+                compute((j + d) & 1);
+                sstore((d + 1) % DEPTH, (j + d + 1) & 1);
+                __syncthreads();
+            }
+        }
     }
 
     // ---- accumulators -> fp32 C image in LDS (lane holds 4 consecutive n of one m)
@@ -391,6 +449,17 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
             *(f32x4*)(cl + m * CLD + n) = acc[mt][nt];
         }
     __syncthreads();
+    if constexpr (GROUPED) {
+        if (colsum && fq == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int gm = m0 + wm * 64 + mt * 16 + fr;
+                if (gm < p.M) p.colsum[gm] = accb[mt][0];
+            }
+        }
+        epi_rows128<STDIFF_EPI_BIAS, T>(p, cl, tid, m0, n0);
+        return;
+    }
     if (p.ksplit > 1) {                 // partial product -> workspace slice; splitk_reduce_kernel finishes the job
         float* w = p.ws + (size_t)split * p.M * p.ldws;
 #pragma unroll 1
@@ -412,6 +481,53 @@ __global__ __launch_bounds__(NT, 2) void gemm_nt_kernel(Params p) {
         const int gm = m0 + r, gn = n0 + c4;
         if (gm < p.M && gn < p.N) epilogue4_slow<T>(p, gm, gn, *(const f32x4*)(cl + r * CLD + c4));
     }
+}
+
+template <typename T, bool AK, bool WK, int DEPTH = 1>
+__global__ __launch_bounds__(NT, DEPTH == 1 ? 2 : 1) void gemm_nt_kernel(Params p) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[smem128<T>()];
+    gemm_nt_body<T, AK, WK, DEPTH, false>(p, blockIdx.x, smem);
+}
+
+// Several weight-gradient products of one batch in ONE launch: gw_i[M_i, N_i] = dY_i^T X_i, gb_i = colsum(dY_i), all
+// over the same K = cells, both operands read K-major as they lie.  A DiT block's five products are 1152 tiles at
+// H = 1024 -- four rounds of the chip with two blocks per CU, so no K split, no reduce pass and no separate column-sum
+// launch (15 launches become 1).  Problem i owns blocks [end_{i-1}, end_i), each range rounded up to a multiple of 8 so
+// that the XCD-aware tile walk of every problem starts on XCD 0; the padding blocks exit at once.
+constexpr int DW_MAX = 8;
+struct DwProblem {
+    int M, N;
+    const void* A; int lda;
+    const void* W; int ldw;
+    float* C; int ldc;
+    float* colsum;
+    int tiles_m, tiles_n, blk_end;
+};
+struct DwGroup {
+    int n, K, k_valid;
+    DwProblem pr[DW_MAX];
+};
+template <typename T>
+__global__ __launch_bounds__(NT, 2) void gemm_dw_group_kernel(DwGroup g) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[smem128<T>()];
+    int i = 0, start = 0;
+    const int bid = blockIdx.x;
+#pragma unroll 1
+    while (i + 1 < g.n && bid >= g.pr[i].blk_end) { start = g.pr[i].blk_end; ++i; }
+    const DwProblem& q = g.pr[i];
+    const int local = bid - start;
+    if (local >= q.tiles_m * q.tiles_n) return;
+    Params p;
+    p.M = q.M; p.N = q.N; p.K = g.K;
+    p.A = q.A; p.lda = q.lda; p.W = q.W; p.ldw = q.ldw; p.bias = nullptr;
+    p.C = q.C; p.ldc = q.ldc; p.c_bf16 = 0;
+    p.epi = STDIFF_EPI_BIAS; p.gate = nullptr; p.ldgate = 0; p.res = nullptr; p.ldres = 0;
+    p.C2 = nullptr; p.ldc2 = 0; p.vec = 1;
+    p.tiles_m = q.tiles_m; p.tiles_n = q.tiles_n; p.k_valid = g.k_valid;
+    p.ksplit = 1; p.nk_per = g.K / Cfg<T>::BK; p.ws = nullptr; p.ldws = 0;
+    p.t_full = p.units = 0; p.ln_parts = nullptr; p.ln_nparts = 0; p.stats_out = nullptr;
+    p.colsum = q.colsum;
+    gemm_nt_body<T, true, true, 1, true>(p, local, smem);
 }
 
 // sum of the split-K partial products in slice order (deterministic) + the full epilogue; one thread = 4 columns
@@ -1598,7 +1714,7 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
 // one process).  Readers never see a half-written record: the pointer is swapped atomically and old records are left
 // alive (a few dozen bytes each).
 struct GemmEnv {
-    int tile, cus, split_tail, splitk_max, splitk_blocks, splitk_min;
+    int tile, cus, split_tail, splitk_max, splitk_blocks, splitk_min, depth;
 };
 const GemmEnv* read_gemm_env() {
     auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; };
@@ -1609,6 +1725,7 @@ const GemmEnv* read_gemm_env() {
     e->splitk_max = num("STDIFF_SPLITK_MAX", 0);
     e->splitk_blocks = num("STDIFF_SPLITK_BLOCKS", 0);
     e->splitk_min = num("STDIFF_SPLITK_MIN", 0);
+    e->depth = num("STDIFF_GEMM_DEPTH", 0);      // 1 / 3: force the 128 x 128 kernel's prefetch depth (A/B timing, tests)
     return e;
 }
 const GemmEnv* g_gemm_env = nullptr;
@@ -1706,7 +1823,7 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
     p.C = a->C; p.ldc = a->ldc; p.c_bf16 = a->c_dtype == STDIFF_BF16;
     p.epi = a->epi; p.gate = a->gate; p.ldgate = a->ldgate; p.res = a->res; p.ldres = a->ldres;
     p.C2 = a->C2; p.ldc2 = a->ldc2;
-    p.ln_parts = a->ln_parts; p.ln_nparts = a->ln_nparts; p.stats_out = a->stats_out;
+    p.ln_parts = a->ln_parts; p.ln_nparts = a->ln_nparts; p.stats_out = a->stats_out; p.colsum = nullptr;
     // 4-wide pieces: fp32 needs 16-byte, bf16 8-byte alignment of every row piece
     bool vec = a->N % 8 == 0 && a->ldc % 4 == 0 && (p.c_bf16 ? al8(a->C) : al16(a->C)) && (!a->bias || al16(a->bias));
     if (a->epi == STDIFF_EPI_GATE_RES)
@@ -1801,12 +1918,20 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
         }
         grid.x = min((int)grid.x, cus);
     }
+    // few blocks (at most one per CU): nothing else on the CU hides the operand latency -> three slabs in flight
+    const int depth_env = env.depth;
+    const bool deep = tile == 1 && (depth_env == 3 || (depth_env == 0 && (long)grid.x <= (long)cu_count()));
+#define STDIFF_LAUNCH128_D(T, D)                                                                               \
+    do {                                                                                                       \
+        if (ak && wk) hipLaunchKernelGGL((gemm_nt_kernel<T, true, true, D>), grid, block, 0, (hipStream_t)stream, p);     \
+        else if (ak) hipLaunchKernelGGL((gemm_nt_kernel<T, true, false, D>), grid, block, 0, (hipStream_t)stream, p);     \
+        else if (wk) hipLaunchKernelGGL((gemm_nt_kernel<T, false, true, D>), grid, block, 0, (hipStream_t)stream, p);     \
+        else hipLaunchKernelGGL((gemm_nt_kernel<T, false, false, D>), grid, block, 0, (hipStream_t)stream, p);            \
+    } while (0)
 #define STDIFF_LAUNCH128(T)                                                                                    \
     do {                                                                                                       \
-        if (ak && wk) hipLaunchKernelGGL((gemm_nt_kernel<T, true, true>), grid, block, 0, (hipStream_t)stream, p);        \
-        else if (ak) hipLaunchKernelGGL((gemm_nt_kernel<T, true, false>), grid, block, 0, (hipStream_t)stream, p);        \
-        else if (wk) hipLaunchKernelGGL((gemm_nt_kernel<T, false, true>), grid, block, 0, (hipStream_t)stream, p);        \
-        else hipLaunchKernelGGL((gemm_nt_kernel<T, false, false>), grid, block, 0, (hipStream_t)stream, p);               \
+        if (deep) STDIFF_LAUNCH128_D(T, 3);                                                                    \
+        else STDIFF_LAUNCH128_D(T, 1);                                                                         \
     } while (0)
     if (!bf)
         STDIFF_LAUNCH128(float);
@@ -1833,6 +1958,35 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
     return STDIFF_OK;
 }
 }  // namespace
+
+// The weight gradients of several linear layers over one batch, one launch (gemm_dw_group_kernel).
+extern "C" int stdiff_dw_group(const stdiff_dw_group_args* a, void* stream) {
+    STDIFF_CHECK_ARG(a != nullptr && a->n >= 1 && a->n <= STDIFF_DW_GROUP_MAX && a->C >= 0);
+    STDIFF_CHECK_ARG(a->dtype == STDIFF_F32 || a->dtype == STDIFF_BF16);
+    if (a->C == 0) return STDIFF_OK;
+    const bool bf = a->dtype == STDIFF_BF16;
+    const int bk = bf ? 64 : 16, epv = bf ? 8 : 4;
+    DwGroup g;
+    g.n = a->n; g.k_valid = a->C; g.K = (a->C + bk - 1) / bk * bk;
+    int end = 0;
+    for (int i = 0; i < a->n; ++i) {
+        const stdiff_dw_problem& q = a->p[i];
+        STDIFF_CHECK_ARG(q.M > 0 && q.N > 0 && q.dY && q.X && q.gw && q.lddy >= q.M && q.ldx >= q.N && q.ldgw >= q.N);
+        if (q.M % epv || q.N % 8) return STDIFF_ERR_SHAPE;          // 16-byte column pieces; 8-column epilogue pieces
+        if (q.lddy % epv || q.ldx % epv || q.ldgw % 4 || !al16(q.dY) || !al16(q.X) || !al16(q.gw)) return STDIFF_ERR_ALIGN;
+        DwProblem& d = g.pr[i];
+        d.M = q.M; d.N = q.N; d.A = q.dY; d.lda = q.lddy; d.W = q.X; d.ldw = q.ldx; d.C = q.gw; d.ldc = q.ldgw;
+        d.colsum = q.gb;
+        d.tiles_m = cdiv(q.M, BM); d.tiles_n = cdiv(q.N, BN);
+        end += (d.tiles_m * d.tiles_n + 7) & ~7;
+        d.blk_end = end;
+    }
+    for (int i = a->n; i < DW_MAX; ++i) g.pr[i] = DwProblem{};
+    if (bf) hipLaunchKernelGGL(gemm_dw_group_kernel<bf16_t>, dim3(end), dim3(NT), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(gemm_dw_group_kernel<float>, dim3(end), dim3(NT), 0, (hipStream_t)stream, g);
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}
 
 #ifdef STDIFF_T192_STAMPS
 extern "C" int stdiff_debug_t192_stamps(unsigned long long* host_out) {

@@ -138,6 +138,29 @@ struct Ctx {
            int x_cols) {
         return dW(l, m, n, dY, lddy, dy_cols, X, ldx, x_cols, [](bool) { return (int)STDIFF_OK; });
     }
+    // Several weight gradients in ONE launch (stdiff_dw_group) + `then`, forked like dW() but NOT joined here: the
+    // grouped backward keeps two sets of dY buffers and calls join() itself where the older set is first rewritten.
+    template <typename Then>
+    int group(const stdiff_dw_group_args& g, Then then) {
+        if (!forking) {
+            TRY(stdiff_dw_group(&g, main));
+            return then(false);
+        }
+        TRYH(hipEventRecord(ev[0], main));
+        TRYH(hipStreamWaitEvent(side, ev[0], 0));
+        TRY(stdiff_dw_group(&g, side));
+        TRY(then(true));
+        TRYH(hipEventRecord(ev[1 + done_i], side));
+        have_prev = true;
+        done_i ^= 1;
+        return STDIFF_OK;
+    }
+    static stdiff_dw_problem prob(const stdiff_train_linear& l, int m, int n, const void* dY, int lddy, const void* X,
+                                  int ldx) {
+        stdiff_dw_problem q = {};
+        q.M = m; q.N = n; q.dY = dY; q.lddy = lddy; q.X = X; q.ldx = ldx; q.gw = l.gw; q.ldgw = n; q.gb = l.gb;
+        return q;
+    }
     // the caller's stream waits for every weight gradient issued so far
     int join() {
         if (forking && have_prev) TRYH(hipStreamWaitEvent(main, ev[1 + (done_i ^ 1)], 0));
@@ -150,6 +173,111 @@ int check_common(const stdiff_train_weights* w, const stdiff_train_acts* a) {
     STDIFF_CHECK_ARG(w->dtype == STDIFF_F32 || w->dtype == STDIFF_BF16);
     STDIFF_CHECK_ARG(w->depth >= 0 && w->depth <= MAX_DEPTH && a->C >= 0);
     if (w->heads <= 0 || w->H % w->heads || w->H % 64 || w->Gp % 64 || w->Gp < w->G) return STDIFF_ERR_SHAPE;
+    return STDIFF_OK;
+}
+
+// The backward with ONE weight-gradient launch per DiT block (stdiff_dw_group: five products + five bias gradients,
+// no K split, no reduce pass) instead of five jobs of three launches.  A block's dY operands must then stay live
+// until its group has run, while the dX chain is already one block further: dbr (MLP branch), dbr (attention
+// branch), dupre, dqkv and dmod exist twice and alternate with the block index; the chain waits for the group of
+// block k + 1 just before block k's LayerNorm-1 backward -- the first launch that rewrites that group's buffers --
+// i.e. a whole block after it was forked.  after_bucket(i) is called at those wait points.
+int backward_grouped(Ctx& c, stdiff_bucket_fn after_bucket, void* user) {
+    const stdiff_train_weights* w = c.w;
+    const stdiff_train_acts* a = c.a;
+    hipStream_t stream = c.main;
+    const int dt = w->dtype, H = w->H, G = w->G, Gp = w->Gp, D = w->depth, C = a->C, d = H / w->heads;
+    void* const dbrm[2] = {a->dbr, a->dbr_b[0]};
+    void* const dbra[2] = {a->dbr_b[1], a->dbr_b[2]};
+    void* const dupre[2] = {a->dupre, a->du};
+    void* const dqkv[2] = {a->dqkv, a->dqkv_b};
+    const bool odd_genes = G % 8 != 0;          // in / cond / out layer: no 16-byte column pieces -> the one-job path
+    // ---- final layer (FinalLayer.forward, stDiff_model.py:135-141)
+    if (odd_genes) TRY(c.dW(w->out, G, H, a->deps, Gp, Gp, a->xnf, H, H));
+    TRY(c.dX(false, C, a->deps, Gp, Gp, w->out, G, H, a->dxn, H, dt));
+    if (D > 0) {
+        const stdiff_train_block_acts& sl = a->blocks[D - 1];
+        const int ql = (D - 1) & 1;
+        TRY(stdiff_ln_modulate_bwd_gate(a->dxn, H, dt, a->h_last, H, a->meanf, a->rstdf, col(a->fmod, dt, H), 2 * H, a->dh,
+                                        H, 0, col(a->dfmod, dt, 0), col(a->dfmod, dt, H), 2 * H, col(sl.mod, dt, 5 * H),
+                                        6 * H, sl.pm, H, dbrm[ql], H, col(a->dmod[ql], dt, 5 * H), 6 * H, C, H, stream));
+    } else {
+        TRY(stdiff_ln_modulate_bwd(a->dxn, H, dt, a->h_last, H, a->meanf, a->rstdf, col(a->fmod, dt, H), 2 * H, a->dh, H,
+                                   0, col(a->dfmod, dt, 0), col(a->dfmod, dt, H), 2 * H, C, H, stream));
+    }
+    {
+        stdiff_dw_group_args g = {};
+        g.C = C; g.dtype = dt;
+        g.p[g.n++] = Ctx::prob(w->fada, 2 * H, H, a->dfmod, 2 * H, a->s, H);
+        if (!odd_genes) g.p[g.n++] = Ctx::prob(w->out, G, H, a->deps, Gp, a->xnf, H);
+        // d loss / d s accumulates over all adaLN projections on the stream that runs the groups, in issue order
+        TRY(c.group(g, [&](bool sd) {
+            return c.dX(sd, C, a->dfmod, 2 * H, 2 * H, w->fada, 2 * H, H, a->ds32, H, STDIFF_F32);
+        }));
+    }
+    for (int k = D - 1; k >= 0; --k) {
+        const stdiff_train_block& b = w->blocks[k];
+        const stdiff_train_block_acts& s = a->blocks[k];
+        const int q = k & 1;
+        void* dmod = a->dmod[q];
+        // MLP branch (DiTblock.forward, stDiff_model.py:116); GELU backward in the fc2 dX epilogue
+        TRY(c.dX(false, C, dbrm[q], H, H, b.fc2, H, 4 * H, dupre[q], 4 * H, dt, STDIFF_EPI_GELU_BWD, s.upre, 4 * H));
+        TRY(c.dX(false, C, dupre[q], 4 * H, 4 * H, b.fc1, 4 * H, H, a->dxn, H, dt));
+        // LayerNorm 2 backward + the attention branch's gate (:114)
+        TRY(stdiff_ln_modulate_bwd_gate(a->dxn, H, dt, s.hmid, H, s.mean2, s.rstd2, col(s.mod, dt, 4 * H), 6 * H, a->dh, H, 1,
+                                        col(dmod, dt, 3 * H), col(dmod, dt, 4 * H), 6 * H, col(s.mod, dt, 2 * H), 6 * H, s.pa,
+                                        H, dbra[q], H, col(dmod, dt, 2 * H), 6 * H, C, H, stream));
+        TRY(c.dX(false, C, dbra[q], H, H, b.proj, H, H, a->do_, H, dt));
+        TRY(stdiff_attention_bwd(s.qkv, 3 * H, s.o, H, a->do_, H, s.lse, a->delta, dqkv[q], 3 * H, a->cu_rows, 1, C, C,
+                                 w->heads, d, dt, stream));
+        TRY(c.dX(false, C, dqkv[q], 3 * H, 3 * H, b.qkv, 3 * H, H, a->dxn, H, dt));
+        // the group forked a block ago (block k + 1, or the final layer's) has read the buffers of the other parity
+        TRY(c.join());
+        if (after_bucket) after_bucket(D - 1 - k, user);
+        if (k > 0) {        // LayerNorm 1 backward + the MLP gate of the block below (the other parity's buffers)
+            const stdiff_train_block_acts& sb = a->blocks[k - 1];
+            TRY(stdiff_ln_modulate_bwd_gate(a->dxn, H, dt, s.h, H, s.mean1, s.rstd1, col(s.mod, dt, H), 6 * H, a->dh, H, 1,
+                                            col(dmod, dt, 0), col(dmod, dt, H), 6 * H, col(sb.mod, dt, 5 * H), 6 * H, sb.pm,
+                                            H, dbrm[q ^ 1], H, col(a->dmod[q ^ 1], dt, 5 * H), 6 * H, C, H, stream));
+        } else {
+            TRY(stdiff_ln_modulate_bwd(a->dxn, H, dt, s.h, H, s.mean1, s.rstd1, col(s.mod, dt, H), 6 * H, a->dh, H, 1,
+                                       col(dmod, dt, 0), col(dmod, dt, H), 6 * H, C, H, stream));
+        }
+        stdiff_dw_group_args g = {};
+        g.C = C; g.dtype = dt;
+        g.p[g.n++] = Ctx::prob(b.ada, 6 * H, H, dmod, 6 * H, a->s, H);
+        g.p[g.n++] = Ctx::prob(b.fc1, 4 * H, H, dupre[q], 4 * H, s.xn2, H);
+        g.p[g.n++] = Ctx::prob(b.fc2, H, 4 * H, dbrm[q], H, s.u, 4 * H);
+        g.p[g.n++] = Ctx::prob(b.qkv, 3 * H, H, dqkv[q], 3 * H, s.xn1, H);
+        g.p[g.n++] = Ctx::prob(b.proj, H, H, dbra[q], H, s.o, H);
+        TRY(c.group(g, [&](bool sd) {
+            return c.dX(sd, C, dmod, 6 * H, 6 * H, b.ada, 6 * H, H, a->ds32, H, STDIFF_F32, STDIFF_EPI_ACCUM);
+        }));
+    }
+    TRY(c.join());                                 // the last group: ds32 is complete
+    if (after_bucket) after_bucket(D, user);
+    // ---- embeddings: h0 = in_layer(x); c = time_emb(t) + cond_layer(y); s = silu(c)   (:231-239)
+    TRY(stdiff_pack_rows(a->dh, H, a->dhT, H, dt, C, H, H, stream));
+    TRY(stdiff_silu_bwd(a->ds32, H, STDIFF_F32, a->c, H, STDIFF_F32, a->dc, H, STDIFF_F32, 0, C, H, stream));
+    TRY(stdiff_pack_rows(a->dc, H, a->dcT, H, dt, C, H, H, stream));
+    TRY(c.dX(false, C, a->dcT, H, H, w->t2, H, H, a->de1, H, dt));
+    TRY(stdiff_silu_bwd(a->de1, H, dt, a->a1, H, dt, a->da1, H, dt, 0, C, H, stream));
+    {
+        stdiff_dw_group_args g = {};
+        g.C = C; g.dtype = dt;
+        g.p[g.n++] = Ctx::prob(w->t2, H, H, a->dcT, H, a->e1, H);
+        g.p[g.n++] = Ctx::prob(w->t0, H, 256, a->da1, H, a->e0, 256);
+        if (!odd_genes) {
+            g.p[g.n++] = Ctx::prob(w->in, H, G, a->dhT, H, a->xp, Gp);
+            g.p[g.n++] = Ctx::prob(w->cond, H, G, a->dcT, H, a->yp, Gp);
+        }
+        TRY(stdiff_dw_group(&g, stream));
+        if (odd_genes) {
+            TRY(c.dW_enqueue(false, w->in, H, G, a->dhT, H, H, a->xp, Gp, Gp));
+            TRY(c.dW_enqueue(false, w->cond, H, G, a->dcT, H, H, a->yp, Gp, Gp));
+        }
+    }
+    if (after_bucket) after_bucket(D + 1, user);
     return STDIFF_OK;
 }
 }  // namespace
@@ -232,7 +360,9 @@ extern "C" int stdiff_dit_backward(const stdiff_train_weights* w, const stdiff_t
         STDIFF_CHECK_ARG(a->splitk_ws_side || !a->splitk_ws);
         TRY(events_for_device(&c.ev));
     }
-    // ---- final layer (FinalLayer.forward, stDiff_model.py:135-141)
+    if (a->dbr_b[0] && a->dbr_b[1] && a->dbr_b[2] && a->dqkv_b) return backward_grouped(c, after_bucket, user);
+    // ---- one job per linear layer (callers that did not provide the second set of dY buffers)
+    // final layer (FinalLayer.forward, stDiff_model.py:135-141)
     TRY(c.dW(w->out, G, H, a->deps, Gp, Gp, a->xnf, H, H));
     TRY(c.dX(false, C, a->deps, Gp, Gp, w->out, G, H, a->dxn, H, dt));
     // every LayerNorm backward of the chain is followed by the gated-residual backward of the branch below it: one launch

@@ -65,6 +65,27 @@ def gemm(A, W, bias=None, out=None, out_dtype=None, epi=L.EPI_BIAS, gate=None, r
     return out
 
 
+def dw_group(problems, C_rows=None):
+    """One launch for several weight gradients over the same batch: for each (dY, X, gw, gb[, M]) in `problems`
+    gw[M, N] = dY[:, :M]^T X[:, :N] and gb[M] = colsum(dY[:, :M]) (gb may be None).  dY [C, >= M], X [C, >= N] of the
+    operand dtype, gw / gb fp32, overwritten."""
+    a = L.DwGroupArgs()
+    assert 1 <= len(problems) <= 8
+    first = problems[0][0]
+    a.n, a.C, a.dtype = len(problems), first.shape[0] if C_rows is None else C_rows, dt_of(first)
+    for i, pr in enumerate(problems):
+        dY, X, gw, gb = pr[:4]
+        require_gpu(dY, X, gw, gb)
+        assert dY.dtype == first.dtype and X.dtype == first.dtype and gw.dtype == torch.float32 and gw.is_contiguous()
+        assert dY.shape[0] >= a.C and X.shape[0] >= a.C and dY.stride(1) == 1 and X.stride(1) == 1
+        q = a.p[i]
+        q.M, q.N = (gw.shape[0] if len(pr) < 5 or pr[4] is None else pr[4]), gw.shape[1]
+        assert dY.shape[1] >= q.M and X.shape[1] >= q.N
+        q.dY, q.lddy, q.X, q.ldx = ptr(dY), dY.stride(0), ptr(X), X.stride(0)
+        q.gw, q.ldgw, q.gb = ptr(gw), gw.stride(0), ptr(gb)
+    check(lib_for(first).stdiff_dw_group(C.byref(a), stream()))
+
+
 def transpose(x, out=None, rows_pad=None):
     """out[c, r] = x[r, c]; columns rows..rows_pad-1 of out are zero-filled (K padding of the backward GEMMs)."""
     require_gpu(x, out)
@@ -212,13 +233,24 @@ def attention_bwd(qkv, out, dout, lse, cu_rows, max_chunk, heads, dqkv=None, del
     return dqkv
 
 
-def ln_modulate_bwd(dy, x, mean, rstd, scale, dx, dshift, dscale, accumulate=True):
-    require_gpu(dy, x, mean, rstd, scale, dx, dshift, dscale)
+def ln_modulate_bwd(dy, x, mean, rstd, scale, dx, dshift, dscale, accumulate=True, gate=None, branch=None, dbranch=None,
+                    dgate=None):
+    """LayerNorm + modulate backward; with gate / branch / dbranch / dgate also the gated-residual backward of the
+    branch below it on the finished dx row (dbranch = dx * gate, dgate = dx * branch): one launch instead of two."""
+    require_gpu(dy, x, mean, rstd, scale, dx, dshift, dscale, gate, branch, dbranch, dgate)
     R, H = x.shape
     assert dshift.stride(0) == dscale.stride(0)
-    check(lib_for(dy, scale, dshift).stdiff_ln_modulate_bwd(ptr(dy), dy.stride(0), dt_of(dy), ptr(x), x.stride(0), ptr(mean), ptr(rstd),
-                                       ptr(scale), scale.stride(0), ptr(dx), dx.stride(0), int(accumulate),
-                                       ptr(dshift), ptr(dscale), dshift.stride(0), R, H, stream()))
+    lb = lib_for(dy, scale, dshift)
+    if gate is None:
+        check(lb.stdiff_ln_modulate_bwd(ptr(dy), dy.stride(0), dt_of(dy), ptr(x), x.stride(0), ptr(mean), ptr(rstd),
+                                        ptr(scale), scale.stride(0), ptr(dx), dx.stride(0), int(accumulate),
+                                        ptr(dshift), ptr(dscale), dshift.stride(0), R, H, stream()))
+        return
+    check(lb.stdiff_ln_modulate_bwd_gate(ptr(dy), dy.stride(0), dt_of(dy), ptr(x), x.stride(0), ptr(mean), ptr(rstd),
+                                         ptr(scale), scale.stride(0), ptr(dx), dx.stride(0), int(accumulate),
+                                         ptr(dshift), ptr(dscale), dshift.stride(0), ptr(gate), gate.stride(0),
+                                         ptr(branch), branch.stride(0), ptr(dbranch), dbranch.stride(0), ptr(dgate),
+                                         dgate.stride(0), R, H, stream()))
 
 
 def gate_bwd(dh, gate, branch, dbranch, dgate):

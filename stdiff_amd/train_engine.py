@@ -97,6 +97,9 @@ class TrainCore:
         # Forward and backward are ONE C-ABI enqueue each (stdiff_dit_train_forward / stdiff_dit_backward);
         # STDIFF_TRAIN_ENQUEUE=py issues the same launches one by one from Python (second implementation, tests)
         self.c_enqueue = os.environ.get("STDIFF_TRAIN_ENQUEUE", "c") != "py"
+        # one stdiff_dw_group launch per block for its five weight/bias gradients (STDIFF_TRAIN_GROUPED=0: one job of
+        # three launches per linear layer, the older path, kept for A/B timing and as a second implementation)
+        self.grouped = os.environ.get("STDIFF_TRAIN_GROUPED", "1") != "0"
         self._cw = None
 
     def refresh_weights(self, pack=True):
@@ -134,6 +137,11 @@ class TrainCore:
             du=z(C, 4 * H), dupre=z(C, 4 * H), do=z(C, H), dqkv=z(C, 3 * H), delta=z(C, self.heads, dt=f32),
             ds32=z(C, H, dt=f32), dc=z(C, H, dt=f32), dcT_=z(C, H), de1=z(C, H), da1=z(C, H), dhT_=z(C, H),
         )
+        if self.grouped:
+            # second set of the per-block dY buffers (dbr of either branch, dqkv; `du` twins dupre): one grouped
+            # weight-gradient launch per block runs while the dX chain is already in the next block
+            a["dbr_b"] = [z(C, H) for _ in range(3)]
+            a["dqkv_b"] = z(C, 3 * H)
         if G % 8:
             # odd gene counts: the weight-gradient GEMMs of in / cond / out layer go through transposed copies
             # (_dW_enqueue).  Their scratch is made HERE, one pair per stream that may run such a job, so that nothing
@@ -214,6 +222,10 @@ class TrainCore:
             if "tr" in a:
                 for i in range(2):
                     ca.tr[i][0], ca.tr[i][1] = p(a["tr"][i][0]), p(a["tr"][i][1])
+            if "dbr_b" in a:
+                for i in range(3):
+                    ca.dbr_b[i] = p(a["dbr_b"][i])
+                ca.dqkv_b = p(a["dqkv_b"])
             ca.splitk_ws, ca.splitk_bytes = p(self.ws_splitk), self.ws_splitk.numel() * 4
             a["_c"] = ca = (ca, blocks)
         ca = ca[0]
@@ -336,9 +348,104 @@ class TrainCore:
                        w_kmajor=True, side=side)
         ops.colsum(dY[:, :m] if rows is not None else dY, self.g[name + ".bias"])
 
-    def _dX(self, name, dY, out, epi=L.EPI_BIAS, side=False):
+    def _group(self, problems, then=None):
+        """[(name, dY, X[, rows])]: every weight / bias gradient of the list in ONE launch (ops.dw_group), forked like
+        _dW but not joined: backward() calls _side_join() where the group's buffers are first rewritten."""
+        pr = []
+        for item in problems:
+            name, dY, X = item[:3]
+            pr.append((dY, X, self.g[name + ".weight"], self.g[name + ".bias"], item[3] if len(item) > 3 else None))
+        if not self._side_on:
+            ops.dw_group(pr)
+            if then is not None:
+                then(False)
+            return
+        cur = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        self._side.wait_event(ready)
+        with torch.cuda.stream(self._side):
+            ops.dw_group(pr)
+            if then is not None:
+                then(True)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        self._side_prev = done
+
+    def _backward_grouped(self, a, after_bucket):
+        """The launch sequence of backward_grouped() in csrc/train_engine.hip, issued from Python."""
+        H, D, G = self.H, self.depth, self.G
+        deps = a["deps"]
+        dbrm, dbra = [a["dbr"], a["dbr_b"][0]], [a["dbr_b"][1], a["dbr_b"][2]]
+        dupre, dqkv = [a["dupre"], a["du"]], [a["dqkv"], a["dqkv_b"]]
+        odd = G % 8 != 0
+        self._side_begin()
+        if odd:
+            self._dW(a, "out_layer.linear", deps, X=a["xnf"], rows=G)
+        self._dX("out_layer.linear", deps, a["dxn"])
+        if D > 0:
+            ql = (D - 1) & 1
+            ops.ln_modulate_bwd(a["dxn"], a["h"][D], a["meanf"], a["rstdf"], a["fmod"][:, H:2 * H], a["dh"],
+                                a["dfmod"][:, 0:H], a["dfmod"][:, H:2 * H], accumulate=False,
+                                gate=a["mod"][D - 1][:, 5 * H:6 * H], branch=a["pm"][D - 1], dbranch=dbrm[ql],
+                                dgate=a["dmod"][ql][:, 5 * H:6 * H])
+        else:
+            ops.ln_modulate_bwd(a["dxn"], a["h"][D], a["meanf"], a["rstdf"], a["fmod"][:, H:2 * H], a["dh"],
+                                a["dfmod"][:, 0:H], a["dfmod"][:, H:2 * H], accumulate=False)
+        first = [("out_layer.adaLN_modulation.1", a["dfmod"], a["s"])]
+        if not odd:
+            first.append(("out_layer.linear", deps, a["xnf"], G))
+        self._group(first, then=lambda sd: self._dX("out_layer.adaLN_modulation.1", a["dfmod"], a["ds32"], side=sd))
+        for k in range(D - 1, -1, -1):
+            p, q = f"blks.{k}.", k & 1
+            mod, dmod = a["mod"][k], a["dmod"][q]
+            self._dX(p + "mlp.fc2", dbrm[q], dupre[q], epi=L.EPI_GELU_BWD, gate=a["upre"][k])
+            self._dX(p + "mlp.fc1", dupre[q], a["dxn"])
+            ops.ln_modulate_bwd(a["dxn"], a["hmid"][k], a["mean2"][k], a["rstd2"][k], mod[:, 4 * H:5 * H], a["dh"],
+                                dmod[:, 3 * H:4 * H], dmod[:, 4 * H:5 * H], accumulate=True,
+                                gate=mod[:, 2 * H:3 * H], branch=a["pa"][k], dbranch=dbra[q], dgate=dmod[:, 2 * H:3 * H])
+            self._dX(p + "attn.proj", dbra[q], a["do"])
+            ops.attention_bwd(a["qkv"][k], a["o"][k], a["do"], a["lse"][k], a["cu"], a["C"], self.heads,
+                              dqkv=dqkv[q], delta=a["delta"])
+            self._dX(p + "attn.qkv", dqkv[q], a["dxn"])
+            self._side_join()
+            if after_bucket:
+                after_bucket(D - 1 - k)
+            if k > 0:
+                ops.ln_modulate_bwd(a["dxn"], a["h"][k], a["mean1"][k], a["rstd1"][k], mod[:, H:2 * H], a["dh"],
+                                    dmod[:, 0:H], dmod[:, H:2 * H], accumulate=True,
+                                    gate=a["mod"][k - 1][:, 5 * H:6 * H], branch=a["pm"][k - 1], dbranch=dbrm[q ^ 1],
+                                    dgate=a["dmod"][q ^ 1][:, 5 * H:6 * H])
+            else:
+                ops.ln_modulate_bwd(a["dxn"], a["h"][k], a["mean1"][k], a["rstd1"][k], mod[:, H:2 * H], a["dh"],
+                                    dmod[:, 0:H], dmod[:, H:2 * H], accumulate=True)
+            self._group([(p + "adaLN_modulation.1", dmod, a["s"]), (p + "mlp.fc1", dupre[q], a["xn2"][k]),
+                         (p + "mlp.fc2", dbrm[q], a["u"][k]), (p + "attn.qkv", dqkv[q], a["xn1"][k]),
+                         (p + "attn.proj", dbra[q], a["o"][k])],
+                        then=lambda sd, p=p, dmod=dmod: self._dX(p + "adaLN_modulation.1", dmod, a["ds32"],
+                                                                 epi=L.EPI_ACCUM, side=sd))
+        self._side_join()
+        if after_bucket:
+            after_bucket(D)
+        ops.pack_rows(a["dh"], H, self.tdt, out=a["dhT_"])
+        ops.silu_bwd(a["ds32"], a["c"], a["dc"])
+        ops.pack_rows(a["dc"], H, self.tdt, out=a["dcT_"])
+        self._dX("time_emb.mlp.2", a["dcT_"], a["de1"])
+        ops.silu_bwd(a["de1"], a["a1"], a["da1"])
+        self._side_on = False
+        last = [("time_emb.mlp.2", a["dcT_"], a["e1"]), ("time_emb.mlp.0", a["da1"], a["e0"])]
+        if not odd:
+            last += [("in_layer.0", a["dhT_"], a["xp"]), ("cond_layer.0", a["dcT_"], a["yp"])]
+        self._group(last)
+        if odd:
+            self._dW_enqueue(a, "in_layer.0", a["dhT_"], a["xp"], None, False)
+            self._dW_enqueue(a, "cond_layer.0", a["dcT_"], a["yp"], None, False)
+        if after_bucket:
+            after_bucket(D + 1)
+
+    def _dX(self, name, dY, out, epi=L.EPI_BIAS, side=False, gate=None):
         """out (+)= dY W  with W [out, in] read K-major (K = out features)."""
-        return self._gemm(dY, self.pw.w[name + ".weight"], None, out=out, epi=epi, w_kmajor=True, side=side)
+        return self._gemm(dY, self.pw.w[name + ".weight"], None, out=out, epi=epi, w_kmajor=True, side=side, gate=gate)
 
     def backward(self, a, after_bucket=None):
         """a['deps'] holds d loss / d eps as the packed operand [C, Gp]; fills self.flat_g (overwrite).
@@ -358,6 +465,8 @@ class TrainCore:
             if err:
                 raise err[0]
             return
+        if "dbr_b" in a:
+            return self._backward_grouped(a, after_bucket)
         deps = a["deps"]
         self._side_begin()
         # ---- final layer

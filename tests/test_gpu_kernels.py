@@ -193,6 +193,32 @@ def test_gemm_k_major_operands(ops, L, dt, M, N, K):
     assert relerr(sub, ref[:sub.shape[0]]) < tol                      # a row subset of a wider K-major operand
 
 
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+@pytest.mark.parametrize("C", [40, 512, 1000])
+def test_dw_group_against_fp32(ops, L, dt, C):
+    """stdiff_dw_group: several weight gradients gw_i = dY_i^T X_i and bias gradients gb_i = colsum(dY_i) over one batch
+    in one launch (ragged tile counts, a row subset of a wider dY, a strided X, one problem without a bias gradient),
+    against the same contractions in fp32 -- and against the one-job path (stdiff_gemm K-major + stdiff_colsum)."""
+    shapes = [(768, 128, 768, 128), (136, 264, 200, 264), (128, 1024, 128, 1024), (8, 8, 8, 8), (264, 72, 264, 80)]
+    prob, refs = [], []
+    for i, (M, N, wy, wx) in enumerate(shapes):
+        dY, X = rnd(C, wy, seed=40 + i), rnd(C, wx, seed=50 + i, scale=C ** -0.5)
+        gw = torch.full((M, N), 7.0, device=DEV)
+        gb = None if i == 3 else torch.full((M,), 7.0, device=DEV)
+        prob.append((to_dt(dY, dt), to_dt(X, dt), gw, gb, M))
+        refs.append((q(dY, dt)[:, :M].T @ q(X, dt)[:, :N], q(dY, dt)[:, :M].sum(0)))
+    ops.dw_group(prob)
+    tol = 3e-6 if dt == "fp32" else 3e-5
+    for (dY, X, gw, gb, M), (rw, rb) in zip(prob, refs):
+        assert relerr(gw, rw) < tol
+        one = ops.gemm(dY, X[:, :gw.shape[1]], None, out_dtype=torch.float32, a_kmajor=True, w_kmajor=True, M=M)
+        assert relerr(gw, one) < tol
+        if gb is not None:
+            assert relerr(gb, rb) < tol
+    with pytest.raises((ValueError, RuntimeError)):          # 16-byte column pieces do not exist for 33 columns
+        ops.dw_group([(prob[0][0], prob[0][1], torch.zeros(33, 128, device=DEV), None, 33)])
+
+
 @pytest.mark.parametrize("variant", ["3", "4", "4s", "4h"])
 @pytest.mark.parametrize("M,N,K", [(600, 520, 256), (257, 264, 64), (1024, 512, 1024), (300, 1000, 192)])
 def test_gemm_256_kernel_all_epilogues(ops, L, M, N, K, variant, gemm_knobs):
