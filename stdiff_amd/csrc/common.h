@@ -111,7 +111,7 @@ __device__ __forceinline__ float gelu_erf_f(float v) { return 0.5f * v * (1.0f +
 // GELU(erf) for bf16 OUTPUTS, 4 lanes at a time, no transcendentals (packs into v_pk_fma_f32): Phi(x) = 0.5 + xc*Q(u),
 // xc = clamp(x, -5, 5), u = 2*xc^2/25 - 1, Q = degree-12 minimax fit (tools/fit_gelu.py).  |Phi - exact| <= 2.6e-7,
 // |gelu - exact| <= 1.3e-6 on [-5, 5] and <= 1.5e-6*|x|/5 beyond: 3 orders below a bf16 ulp of the result scale.
-__device__ __forceinline__ f32x4 gelu_poly4(f32x4 x) {
+__device__ __forceinline__ f32x4 gelu_phi4(f32x4 x) {
     constexpr float c[13] = {1.413637847e-01f, -7.029628009e-02f, 5.152052268e-02f, -4.044260830e-02f,
                              3.144217283e-02f, -2.326865308e-02f, 1.640217379e-02f, -1.116433926e-02f,
                              6.410510279e-03f, -2.685575048e-03f, 1.722799498e-03f, -1.613265136e-03f,
@@ -123,7 +123,17 @@ __device__ __forceinline__ f32x4 gelu_poly4(f32x4 x) {
     f32x4 q = u * c[12] + c[11];
 #pragma unroll
     for (int k = 10; k >= 0; --k) q = q * u + c[k];
-    return x * (xc * q + 0.5f);
+    return xc * q + 0.5f;
+}
+__device__ __forceinline__ f32x4 gelu_poly4(f32x4 x) { return x * gelu_phi4(x); }
+// d gelu / dx = Phi(x) + x * phi(x) for 16-bit OUTPUTS: Phi from the polynomial above, the density through the
+// hardware exp2 (relative error ~1e-7 of a value <= 0.4): far below the output rounding
+__device__ __forceinline__ f32x4 gelu_grad4(f32x4 x) {
+    f32x4 d = gelu_phi4(x);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        d[j] += x[j] * (0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x[j] * x[j]));
+    return d;
 }
 
 // LayerNorm + modulate of one element, written once so that every kernel that applies it (ln_modulate_kernel and the

@@ -96,6 +96,8 @@ template <int EPI, bool FAST = false> __device__ __forceinline__ f32x4 epi_math(
         o = r + g * pre;
     } else if constexpr (EPI == STDIFF_EPI_ADD || EPI == STDIFF_EPI_ACCUM) {
         o = pre + r;
+    } else if constexpr (FAST && EPI == STDIFF_EPI_GELU_BWD) {      // 16-bit result: no erff / expf calls
+        o = pre * gelu_grad4(g);
     } else if constexpr (EPI == STDIFF_EPI_GELU_BWD) {      // g = the saved pre-activation; stdiff_gelu_bwd's expression
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -315,50 +317,60 @@ __device__ __forceinline__ void gemm_nt_body(const Params& p, const int bid, uns
 #pragma unroll
     for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool colsum = GROUPED && p.colsum != nullptr && tn == 0 && wn == 0;
+    // 16-bit operands: the MFMA fragments of K-step ks (32 of the slab's 64 k) of the tile in LDS buffer `buf`
+    auto frags = [&](int buf, int ks, bf16x8 (&af)[4], bf16x8 (&wf)[4]) {
+        const unsigned char* ba = smem + buf * 2 * TILEB;
+        const unsigned char* bw = ba + TILEB;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int ra_ = wm * 64 + t * 16 + fr, rw_ = wn * 64 + t * 16 + fr;
+            int slot = ks * 4 + fq;
+            // K-major: lanes (fr>>2, fr&3) of a 16-lane group address a 4-row x 16-column block whose rows are
+            // k = 32 ks + 8 fq + {0..3} (then +4); the transposed read hands lane fr column fr of that block
+            const int kb = ks * 32 + 8 * fq + (fr >> 2), fk = (kb & 3) | (((kb >> 3) & 1) << 2);
+            if constexpr (AK) {
+                const unsigned char* a0 = ba + kb * 256 + ((((wm * 64 + t * 16) >> 4) ^ fk) << 5) + 8 * (fr & 3);
+                bf16x4 lo = ds_read_tr16_b64(a0);
+                bf16x4 hi = ds_read_tr16_b64(a0 + 4 * 256);
+                af[t] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            } else {
+                af[t] = *(const bf16x8*)(ba + ra_ * ROWB + ((slot ^ C::swz(ra_)) << 4));
+            }
+            if constexpr (WK) {
+                const unsigned char* w0 = bw + kb * 256 + ((((wn * 64 + t * 16) >> 4) ^ fk) << 5) + 8 * (fr & 3);
+                bf16x4 lo = ds_read_tr16_b64(w0);
+                bf16x4 hi = ds_read_tr16_b64(w0 + 4 * 256);
+                wf[t] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            } else {
+                wf[t] = *(const bf16x8*)(bw + rw_ * ROWB + ((slot ^ C::swz(rw_)) << 4));
+            }
+        }
+    };
+    auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&wf)[4]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                acc[mt][nt] = STDIFF_MFMA_16x16x32_H16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+        if constexpr (GROUPED) {
+            if (colsum) {
+                const h16 one = (h16)1.0f;
+                const bf16x8 ones = {one, one, one, one, one, one, one, one};
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) accb[mt] = STDIFF_MFMA_16x16x32_H16(ones, af[mt], accb[mt], 0, 0, 0);
+            }
+        }
+    };
     auto compute = [&](int buf) {
         const unsigned char* ba = smem + buf * 2 * TILEB;
         const unsigned char* bw = ba + TILEB;
+        (void)bw;
         if constexpr (sizeof(T) == 2) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8 af[4], wf[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    int ra_ = wm * 64 + t * 16 + fr, rw_ = wn * 64 + t * 16 + fr;
-                    int slot = ks * 4 + fq;
-                    // K-major: lanes (fr>>2, fr&3) of a 16-lane group address a 4-row x 16-column block whose rows are
-                    // k = 32 ks + 8 fq + {0..3} (then +4); the transposed read hands lane fr column fr of that block
-                    const int kb = ks * 32 + 8 * fq + (fr >> 2), fk = (kb & 3) | (((kb >> 3) & 1) << 2);
-                    if constexpr (AK) {
-                        const unsigned char* a0 = ba + kb * 256 + ((((wm * 64 + t * 16) >> 4) ^ fk) << 5) + 8 * (fr & 3);
-                        bf16x4 lo = ds_read_tr16_b64(a0);
-                        bf16x4 hi = ds_read_tr16_b64(a0 + 4 * 256);
-                        af[t] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    } else {
-                        af[t] = *(const bf16x8*)(ba + ra_ * ROWB + ((slot ^ C::swz(ra_)) << 4));
-                    }
-                    if constexpr (WK) {
-                        const unsigned char* w0 = bw + kb * 256 + ((((wn * 64 + t * 16) >> 4) ^ fk) << 5) + 8 * (fr & 3);
-                        bf16x4 lo = ds_read_tr16_b64(w0);
-                        bf16x4 hi = ds_read_tr16_b64(w0 + 4 * 256);
-                        wf[t] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    } else {
-                        wf[t] = *(const bf16x8*)(bw + rw_ * ROWB + ((slot ^ C::swz(rw_)) << 4));
-                    }
-                }
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        acc[mt][nt] = STDIFF_MFMA_16x16x32_H16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
-                if constexpr (GROUPED) {
-                    if (colsum) {
-                        const h16 one = (h16)1.0f;
-                        const bf16x8 ones = {one, one, one, one, one, one, one, one};
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) accb[mt] = STDIFF_MFMA_16x16x32_H16(ones, af[mt], accb[mt], 0, 0, 0);
-                    }
-                }
+                frags(buf, ks, af, wf);
+                mma(af, wf);
             }
         } else {
             f32x4 af[4], wf[4];
@@ -420,21 +432,64 @@ __device__ __forceinline__ void gemm_nt_body(const Params& p, const int bid, uns
         sstore(0, 0);
         __syncthreads();
         int j = 0;
-        for (; j + DEPTH <= nk; j += DEPTH) {
-#pragma unroll
-            for (int d = 0; d < DEPTH; ++d) {
-                gload(d, min(kb + j + d + DEPTH, last) * BK);
-                compute((j + d) & 1);
-                sstore((d + 1) % DEPTH, (j + d + 1) & 1);
+        if constexpr (sizeof(T) == 2) {
+            // One wave per SIMD: nothing else hides the LDS latency of the fragment reads, so they are software-pipelined
+            // across the barrier -- the second K-step's fragments are read under the first one's 16 MFMAs, and the NEXT
+            // slab's first fragments (from the buffer the barrier has just published) under the second one's.
+            bf16x8 af0[4], wf0[4], af1[4], wf1[4];
+            frags(0, 0, af0, wf0);
+            // sched_barrier(0): the machine scheduler would otherwise hoist the MFMAs that consume the reads just issued
+            // above the ones whose operands are already in registers, exposing the LDS latency again
+            // The LDS store of the next slab (loaded two steps ago) is issued BEFORE the first 16 MFMAs, so that it
+            // drains under them instead of in front of the barrier.
+            auto step = [&](int buf, int next_set, auto prefetch) {
+                frags(buf, 1, af1, wf1);
+                prefetch();
+                sstore(next_set, buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(af0, wf0);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto step2 = [&](int buf) {
                 __syncthreads();
+                frags(buf ^ 1, 0, af0, wf0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(af1, wf1);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            for (; j + DEPTH <= nk; j += DEPTH) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {
+                    const int buf = (j + d) & 1;
+                    step(buf, (d + 1) % DEPTH, [&] { gload(d, min(kb + j + d + DEPTH, last) * BK); });
+                    step2(buf);
+                }
             }
-        }
 #pragma unroll
-        for (int d = 0; d < DEPTH - 1; ++d) {
-            if (j + d < nk) {
-                compute((j + d) & 1);
-                sstore((d + 1) % DEPTH, (j + d + 1) & 1);
-                __syncthreads();
+            for (int d = 0; d < DEPTH - 1; ++d) {
+                if (j + d < nk) {
+                    const int buf = (j + d) & 1;
+                    step(buf, (d + 1) % DEPTH, [] {});
+                    step2(buf);
+                }
+            }
+        } else {
+            for (; j + DEPTH <= nk; j += DEPTH) {
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {
+                    gload(d, min(kb + j + d + DEPTH, last) * BK);
+                    compute((j + d) & 1);
+                    sstore((d + 1) % DEPTH, (j + d + 1) & 1);
+                    __syncthreads();
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < DEPTH - 1; ++d) {
+                if (j + d < nk) {
+                    compute((j + d) & 1);
+                    sstore((d + 1) % DEPTH, (j + d + 1) & 1);
+                    __syncthreads();
+                }
             }
         }
     }
