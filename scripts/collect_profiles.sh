@@ -2,7 +2,7 @@
 # How the files under profiles/ are produced (on the GPU box, from the repository root, through gpurun):
 #   scripts/collect_profiles.sh <tag> [dtype]
 # Output: gpurun_out/<tag>/; tools/pmc_traffic.py, tools/roofline_check.py and tools/mfma_busy.py then make the
-# summaries that are committed under profiles/ as r02_<tag>_*.  Every GPU step has its own time limit; the chain stops
+# summaries that are committed under profiles/ as r<round>_<tag>_*.  Every GPU step has its own time limit; the chain stops
 # at the first failure.  PMC passes run one counter group each, without any trace option.
 set -e
 TAG=${1:-x}
