@@ -131,13 +131,17 @@ def test_clip_adamw_matches_torch():
 
 
 # ---------------------------------------------------------------- whole train step vs the reference goldens
-@pytest.mark.parametrize("use_graph,side", [(False, "1"), (True, "1"), (True, "0"), (False, "2")])
-def test_train_steps_golden_fp32(golden_dir, use_graph, side, monkeypatch):
+@pytest.mark.parametrize("use_graph,side,grouped", [(False, "1", "1"), (True, "1", "1"), (True, "0", "1"),
+                                                    (False, "2", "1"), (True, "1", "0"), (False, "2", "0")])
+def test_train_steps_golden_fp32(golden_dir, use_graph, side, grouped, monkeypatch):
     """3 consecutive reference iterations (G6); use_graph=True replays each as one captured hipGraph, whose weight
     gradients sit on parallel branches (side stream during capture; side="0": single chain; side="2" forks in the
-    eager enqueue too, which exercises the fork / late-join ordering without a graph)."""
+    eager enqueue too, which exercises the fork / late-join ordering without a graph).  grouped="0": one job of three
+    launches per linear layer instead of one stdiff_dw_group launch per block (the path of callers that do not pass
+    the second set of dY buffers)."""
     from stdiff_amd.train_engine import TrainEngine
     monkeypatch.setenv("STDIFF_TRAIN_SIDE_STREAM", side)
+    monkeypatch.setenv("STDIFF_TRAIN_GROUPED", grouped)
     g = np.load(os.path.join(golden_dir, "g6_train.npz"))
     C, G, H, depth, heads, seed, T = [int(v) for v in g["cfg"]]
     m, p0 = build(G, H, depth, heads, seed, "fp32")
