@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define STDIFF_ABI_VERSION 10
+#define STDIFF_ABI_VERSION 11
 
 enum { STDIFF_F32 = 0, STDIFF_BF16 = 1 };
 
@@ -75,6 +75,12 @@ const char* stdiff_error_string(int status);
  * elements and A/W 16-byte aligned; M, N arbitrary. gate has a_dtype, res is fp32.  With ANY epilogue a non-NULL
  * C2 (a_dtype, ldc2) additionally receives v itself -- the training forward keeps pre-activations / branch outputs. */
 enum { STDIFF_ROW_MAJOR = 0, STDIFF_K_MAJOR = 1 };
+/* A GEMM result left as split-K partial products (fp32):  v[m][n] = sum_{s < slices} ws[s * slice_stride + m * ldws + n].
+ * Filled by stdiff_gemm through stdiff_gemm_args.defer; consumed by stdiff_ln_modulate_split,
+ * stdiff_ln_modulate_bwd_split and stdiff_attention_bwd_split, which sum the slices in slice order (deterministic, the
+ * order of the reduce launch they replace).  No counterpart in the reference: it removes a launch from the dependent
+ * chain of a 512-cell training iteration. */
+typedef struct { const float* ws; int ldws; int slices; long long slice_stride; } stdiff_split_result;
 typedef struct {
     int M, N, K;
     const void* A; int lda; int a_dtype;
@@ -104,6 +110,11 @@ typedef struct {
      *   to the residual stream hands the next LayerNorm its statistics, and no pass over C is needed for them. */
     const float* ln_parts; int ln_nparts;
     float* stats_out;
+    /* defer (host pointer, may be NULL): when the launch splits its K axis (few tiles, long K, a workspace) and epi is
+     * STDIFF_EPI_BIAS or STDIFF_EPI_GATE_RES, the reduce launch is SKIPPED, the partial products stay in the workspace
+     * and *defer describes them: the consumer sums the slices and applies the epilogue itself (the *_split entry
+     * points below).  defer->slices == 0 on return: the launch completed normally (C is written). */
+    stdiff_split_result* defer;
 } stdiff_gemm_args;
 int stdiff_gemm(const stdiff_gemm_args* a, void* stream);
 
@@ -246,6 +257,24 @@ int stdiff_ln_modulate_bwd_gate(const void* dy, int lddy, int dtype, const float
                                 const float* rstd, const void* scale, int ldmod, float* dx, int lddx, int accumulate,
                                 void* dshift, void* dscale, int lddmod, const void* gate, int ldgate, const void* branch,
                                 int ldbr, void* dbranch, int lddb, void* dgate, int lddg, int R, int H, void* stream);
+/* The three consumers of a deferred split-K result (stdiff_split_result).  Results equal the unfused sequence
+ * (stdiff_gemm with its reduce launch, then the plain entry point) bit for bit.
+ *  - forward:  v = sum + bias;  x = res + gate * v (gate == NULL: x = v);  v_out (mod_dtype, optional) = v;  then
+ *    stdiff_ln_modulate of x.  (attn.proj / mlp.fc2 with their gated residual, followed by the next LayerNorm.)
+ *  - backward: dy = the sum rounded to `dtype`, then stdiff_ln_modulate_bwd_gate (gate == NULL: stdiff_ln_modulate_bwd).
+ *  - attention backward: dout = the sum rounded to `dtype` (written to `dout`, [R, >= heads*d]), then stdiff_attention_bwd. */
+int stdiff_ln_modulate_split(const stdiff_split_result* sp, const float* bias, const void* gate, int ldgate,
+                             const float* res, int ldres, float* x, int ldx, void* v_out, int ldv, const void* shift,
+                             const void* scale, int ldmod, int mod_dtype, void* y, int ldy, int out_dtype, float* mean,
+                             float* rstd, int R, int H, void* stream);
+int stdiff_ln_modulate_bwd_split(const stdiff_split_result* sp, int dtype, const float* x, int ldx, const float* mean,
+                                 const float* rstd, const void* scale, int ldmod, float* dx, int lddx, int accumulate,
+                                 void* dshift, void* dscale, int lddmod, const void* gate, int ldgate, const void* branch,
+                                 int ldbr, void* dbranch, int lddb, void* dgate, int lddg, int R, int H, void* stream);
+int stdiff_attention_bwd_split(const void* qkv, int ldqkv, const void* out, int ldo, const stdiff_split_result* sp,
+                               void* dout, int lddo, const float* lse, float* delta, void* dqkv, int lddqkv,
+                               const int32_t* cu_rows, int n_chunks, int max_chunk_rows, int total_rows, int heads,
+                               int head_dim, int dtype, void* stream);
 /* gated residual backward: dbranch = dh*gate (dtype), dgate = dh*branch (dtype) ; dh fp32 */
 int stdiff_gate_bwd(const float* dh, int lddh, const void* gate, int ldgate, const void* branch, int ldbr,
                     void* dbranch, int lddb, void* dgate, int lddg, int dtype, int R, int H, void* stream);
@@ -411,6 +440,9 @@ typedef struct {
      * the dY operands of a block (dbr of either branch, dupre with `du` as its twin, dqkv, dmod) then alternate between
      * two sets so that a block's group can run while the chain is already in the next block. */
     void* dbr_b[3]; void* dqkv_b;
+    /* != 0: never leave a GEMM result as split-K partial products for its consumer (stdiff_gemm_args.defer): every split
+     * GEMM is followed by its reduce launch, as before ABI 11 (A/B timing; results are bit-identical either way) */
+    int no_defer;
 } stdiff_train_acts;
 /* side_stream (NULL = none): the adaLN projections of the forward and the weight-gradient jobs of the backward are
  * issued there and joined with events the library creates once per device (hipEventDisableTiming; no device memory):

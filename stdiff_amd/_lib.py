@@ -18,6 +18,11 @@ LIB_PATH_F16 = os.path.join(_HERE, "libstdiff_hip_f16.so")
 vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
 
 
+class SplitResult(C.Structure):
+    """stdiff_split_result: a GEMM result left as split-K partial products (slices == 0: the GEMM completed)."""
+    _fields_ = [("ws", vp), ("ldws", i32), ("slices", i32), ("slice_stride", C.c_longlong)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [("M", i32), ("N", i32), ("K", i32),
                 ("A", vp), ("lda", i32), ("a_dtype", i32),
@@ -30,7 +35,7 @@ class GemmArgs(C.Structure):
                 ("C2", vp), ("ldc2", i32),
                 ("workspace", vp), ("workspace_bytes", C.c_longlong),
                 ("a_layout", i32), ("w_layout", i32), ("k_valid", i32),
-                ("ln_parts", vp), ("ln_nparts", i32), ("stats_out", vp)]
+                ("ln_parts", vp), ("ln_nparts", i32), ("stats_out", vp), ("defer", C.POINTER(SplitResult))]
 
 
 class StepArgs(C.Structure):
@@ -86,7 +91,8 @@ class TrainActs(C.Structure):
                [(n, vp) for n in ("dfmod", "dbr", "du", "dupre", "do_", "dqkv", "delta", "ds32", "dc", "dcT", "de1",
                                   "da1", "dhT")] + \
                [("tr", (vp * 2) * 2), ("splitk_ws", vp), ("splitk_bytes", C.c_longlong),
-                ("splitk_ws_side", vp), ("splitk_side_bytes", C.c_longlong), ("dbr_b", vp * 3), ("dqkv_b", vp)]
+                ("splitk_ws_side", vp), ("splitk_side_bytes", C.c_longlong), ("dbr_b", vp * 3), ("dqkv_b", vp),
+                ("no_defer", i32)]
 
 
 class DwProblem(C.Structure):
@@ -134,6 +140,12 @@ _SIGS = {
     "stdiff_init_sample": (i32, [vp, vp, u64, i64, vp, vp, vp, i32, i32, i32, i32, vp]),
     "stdiff_add_noise_splice": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "stdiff_masked_mse": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f32, i32, i32, vp]),
+    "stdiff_ln_modulate_split": (i32, [C.POINTER(SplitResult), vp, vp, i32, vp, i32, vp, i32, vp, i32, vp, vp, i32, i32, vp,
+                                       i32, i32, vp, vp, i32, i32, vp]),
+    "stdiff_ln_modulate_bwd_split": (i32, [C.POINTER(SplitResult), i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, vp, vp, i32,
+                                           vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, vp]),
+    "stdiff_attention_bwd_split": (i32, [vp, i32, vp, i32, C.POINTER(SplitResult), vp, i32, vp, vp, vp, i32, vp, i32, i32,
+                                         i32, i32, i32, i32, vp]),
     "stdiff_attention_bwd": (i32, [vp, i32, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp]),
     "stdiff_ln_modulate_bwd": (i32, [vp, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, vp, vp, i32, i32, i32, vp]),
     "stdiff_ln_modulate_bwd_gate": (i32, [vp, i32, i32, vp, i32, vp, vp, vp, i32, vp, i32, i32, vp, vp, i32,
@@ -175,7 +187,7 @@ def lib(fp16=False):
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.stdiff_abi_version() != 10:
+        if L.stdiff_abi_version() != 11:
             raise RuntimeError(f"{base} ABI version mismatch")
         if L.stdiff_h16_format() != int(bool(fp16)):
             raise RuntimeError(f"{base} was built with the wrong 16-bit operand format")

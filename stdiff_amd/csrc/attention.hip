@@ -311,15 +311,30 @@ __global__ __launch_bounds__(256, ATTN_FWD_OCC) void attn_fwd_kernel(const T* __
 
 // ================================================================ backward
 // delta[r, h] = sum_d dO[r, hD+d] * O[r, hD+d]
-template <typename T>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const T* o, int ldo, const T* dout, int lddo, float* delta,
-                                                         int R, int heads, int D) {
+// SPLIT: dout still lies as split-K partial products of the projection's input-gradient GEMM (stdiff_split_result): the
+// wave sums its piece in slice order, rounds it to T, WRITES it to dout (the dQ / dK / dV passes read it from there) and
+// goes on with the rounded values -- the bits the reduce launch it replaces would have left.
+template <typename T, bool SPLIT = false>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* o, int ldo, T* dout, int lddo, float* delta,
+                                                         int R, int heads, int D, const float* ws, int ldws, int slices,
+                                                         long long stride) {
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);      // one wave per (row, head)
     if (idx >= R * heads) return;
     const int r = idx / heads, h = idx % heads, lane = threadIdx.x & 63;
     float s = 0.f;
     for (int c = lane * 4; c < D; c += 256) {
-        f32x4 a = ld4(o + (size_t)r * ldo + h * D + c), b = ld4(dout + (size_t)r * lddo + h * D + c);
+        f32x4 a = ld4(o + (size_t)r * ldo + h * D + c), b;
+        if constexpr (SPLIT) {
+            const float* w = ws + (size_t)r * ldws + h * D + c;
+            b = sum_slices(w, slices, stride);
+            st4(dout + (size_t)r * lddo + h * D + c, b);
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = bf2f(f2bf(b[j]));
+            }
+        } else {
+            b = ld4(dout + (size_t)r * lddo + h * D + c);
+        }
         s += (a[0] * b[0] + a[1] * b[1]) + (a[2] * b[2] + a[3] * b[3]);
     }
     s = wave_sum(s);
@@ -501,11 +516,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
 }
 
 template <typename T>
-int launch_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const void* dout, int lddo, const float* lse,
+int launch_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const void* dout_, int lddo, const float* lse,
                float* delta, void* dqkv, int lddqkv, const int32_t* cu, int n_chunks, int maxc, int R, int heads, int d,
-               hipStream_t st) {
-    hipLaunchKernelGGL(attn_delta_kernel<T>, dim3(cdiv((long)R * heads, 4)), dim3(256), 0, st, (const T*)out, ldo,
-                       (const T*)dout, lddo, delta, R, heads, d);
+               hipStream_t st, const stdiff_split_result* sp = nullptr) {
+    void* dout = const_cast<void*>(dout_);          // written only when it is formed here from `sp`
+    if (sp)
+        hipLaunchKernelGGL((attn_delta_kernel<T, true>), dim3(cdiv((long)R * heads, 4)), dim3(256), 0, st, (const T*)out,
+                           ldo, (T*)dout, lddo, delta, R, heads, d, sp->ws, sp->ldws, sp->slices, sp->slice_stride);
+    else
+        hipLaunchKernelGGL((attn_delta_kernel<T, false>), dim3(cdiv((long)R * heads, 4)), dim3(256), 0, st, (const T*)out,
+                           ldo, (T*)dout, lddo, delta, R, heads, d, (const float*)nullptr, 0, 0, 0ll);
     dim3 grid(2 * cdiv(maxc, BQ), heads, n_chunks), block(256);
     const float scale = 1.0f / sqrtf((float)d), c = scale * 1.4426950408889634f;
 #define CASE(DD)                                                                                                  \
@@ -566,4 +586,26 @@ extern "C" int stdiff_attention_bwd(const void* qkv, int ldqkv, const void* out,
                                   max_chunk_rows, total_rows, heads, head_dim, (hipStream_t)stream);
     return launch_bwd<float>(qkv, ldqkv, out, ldo, dout, lddo, lse, delta, dqkv, lddqkv, cu_rows, n_chunks,
                              max_chunk_rows, total_rows, heads, head_dim, (hipStream_t)stream);
+}
+
+extern "C" int stdiff_attention_bwd_split(const void* qkv, int ldqkv, const void* out, int ldo,
+                                          const stdiff_split_result* sp, void* dout, int lddo, const float* lse,
+                                          float* delta, void* dqkv, int lddqkv, const int32_t* cu_rows, int n_chunks,
+                                          int max_chunk_rows, int total_rows, int heads, int head_dim, int dtype,
+                                          void* stream) {
+    STDIFF_CHECK_ARG(sp && sp->ws && sp->slices >= 1 && sp->slices <= STDIFF_MAX_SLICES && sp->ldws >= heads * head_dim);
+    STDIFF_CHECK_ARG(out && dout && lse && delta && dqkv && total_rows >= 0);
+    int rc = check_common(qkv, ldqkv, ldo, cu_rows, n_chunks, max_chunk_rows, heads, head_dim, dtype);
+    if (rc != STDIFF_OK) return rc;
+    const int epv = dtype == STDIFF_BF16 ? 8 : 4;
+    if (lddo % epv || lddqkv % epv || ((uintptr_t)out & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 15) ||
+        sp->ldws % 4 || sp->slice_stride % 4 || ((uintptr_t)sp->ws & 15))
+        return STDIFF_ERR_ALIGN;
+    if (lddo < heads * head_dim || lddqkv < 3 * heads * head_dim) return STDIFF_ERR_ARG;
+    if (n_chunks == 0 || max_chunk_rows == 0 || total_rows == 0) return STDIFF_OK;
+    if (dtype == STDIFF_BF16)
+        return launch_bwd<bf16_t>(qkv, ldqkv, out, ldo, dout, lddo, lse, delta, dqkv, lddqkv, cu_rows, n_chunks,
+                                  max_chunk_rows, total_rows, heads, head_dim, (hipStream_t)stream, sp);
+    return launch_bwd<float>(qkv, ldqkv, out, ldo, dout, lddo, lse, delta, dqkv, lddqkv, cu_rows, n_chunks,
+                             max_chunk_rows, total_rows, heads, head_dim, (hipStream_t)stream, sp);
 }

@@ -150,6 +150,22 @@ __device__ __forceinline__ float ln_mod_apply_pre(float v, float mean, float rst
     return __builtin_fmaf(t, one_plus_scale, shift);
 }
 
+// Sum of split-K partial products in slice order (the order of splitk_reduce_kernel), with every slice's load issued
+// before the first add: the consumers that call this run one wave per row at two waves per CU, where a chain of
+// dependent loads would cost a memory round trip per slice.  slices <= STDIFF_MAX_SLICES (the host's split limit).
+#define STDIFF_MAX_SLICES 16
+__device__ __forceinline__ f32x4 sum_slices(const float* w, int slices, long long stride) {
+    f32x4 part[STDIFF_MAX_SLICES];
+#pragma unroll
+    for (int k = 0; k < STDIFF_MAX_SLICES; ++k)
+        if (k < slices) part[k] = *(const f32x4*)(w + (size_t)k * stride);
+    f32x4 a = part[0];
+#pragma unroll
+    for (int k = 1; k < STDIFF_MAX_SLICES; ++k)
+        if (k < slices) a += part[k];
+    return a;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -1839,6 +1839,7 @@ extern "C" int stdiff_gemm_static_scratch(const stdiff_gemm_args* a, void* strea
 namespace {
 int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long long workspace_bytes, bool strict_ws) {
     STDIFF_CHECK_ARG(a && a->M >= 0 && a->N >= 0 && a->K > 0);
+    if (a->defer) a->defer->slices = 0;
     if (a->M == 0 || a->N == 0) return STDIFF_OK;          // an empty shard: nothing to do (pointers may be null)
     STDIFF_CHECK_ARG(a->A && a->W && a->C);
     STDIFF_CHECK_ARG(a->a_dtype == STDIFF_F32 || a->a_dtype == STDIFF_BF16);
@@ -2004,7 +2005,12 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
         hipLaunchKernelGGL(gemm256q_kernel<0>, grid, block, 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(gemm256p_kernel, grid, block, 0, (hipStream_t)stream, p);
-    if (p.ksplit > 1) {
+    if (a->defer) a->defer->slices = 0;
+    if (p.ksplit > 1 && a->defer && (a->epi == STDIFF_EPI_BIAS || a->epi == STDIFF_EPI_GATE_RES)) {
+        // the consumer sums the slices (stdiff_*_split): no reduce launch
+        a->defer->ws = p.ws; a->defer->ldws = p.ldws; a->defer->slices = p.ksplit;
+        a->defer->slice_stride = (long long)p.M * p.ldws;
+    } else if (p.ksplit > 1) {
         dim3 rg(cdiv((long)p.M * (p.ldws >> 2), 256));
         if (bf) hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, rg, dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(splitk_reduce_kernel<float>, rg, dim3(256), 0, (hipStream_t)stream, p);

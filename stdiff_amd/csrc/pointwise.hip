@@ -7,10 +7,18 @@ namespace {
 
 // ---------------------------------------------------------------- LayerNorm + modulate (stDiff_model.py:41-44,96,99,126)
 // NV = float4 vectors per lane: H <= 256*NV.
-template <int NV, typename TM, typename TO>
+// SPLIT: x is not read but FORMED from a GEMM result that still lies as split-K partial products (stdiff_split_result):
+// v = sum of the slices + bias, x = res + gate * v (no gate: x = v); x and v are written for the backward pass.  The
+// arithmetic and its order are those of splitk_reduce_kernel's gated-residual epilogue, so nothing changes but the launch.
+struct LnSplit {
+    const float* ws; int ldws, slices; long long stride;
+    const float* bias; const void* gate; int ldgate; const float* res; int ldres;
+    float* x_out; int ldxo; void* v_out; int ldv;
+};
+template <int NV, typename TM, typename TO, bool SPLIT = false>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, int ldx, const TM* shift,
                                                           const TM* scale, int ldmod, TO* y, int ldy, float* mean_out,
-                                                          float* rstd_out, int R, int H) {
+                                                          float* rstd_out, int R, int H, LnSplit sp) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= R) return;
@@ -20,7 +28,25 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         int c = (i * 64 + lane) * 4;
-        v[i] = c < H ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (SPLIT) {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < H) {
+                const float* w = sp.ws + (size_t)row * sp.ldws + c;
+                f32x4 a = sum_slices(w, sp.slices, sp.stride);
+                if (sp.bias) a += *(const f32x4*)(sp.bias + c);
+                if (sp.v_out) st4((TM*)sp.v_out + (size_t)row * sp.ldv + c, a);
+                if (sp.gate) {
+                    const f32x4 g = ld4((const TM*)sp.gate + (size_t)row * sp.ldgate + c);
+                    const f32x4 r = *(const f32x4*)(sp.res + (size_t)row * sp.ldres + c);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) a[j] = r[j] + g[j] * a[j];
+                }
+                *(f32x4*)(sp.x_out + (size_t)row * sp.ldxo + c) = a;
+                v[i] = a;
+            }
+        } else {
+            v[i] = c < H ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
     const float mean = wave_sum(s) / (float)H;
@@ -59,11 +85,17 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restric
 
 template <typename TM, typename TO>
 int launch_ln(const float* x, int ldx, const void* shift, const void* scale, int ldmod, void* y, int ldy, float* mean,
-              float* rstd, int R, int H, hipStream_t st) {
+              float* rstd, int R, int H, hipStream_t st, const LnSplit* sp = nullptr) {
     dim3 grid(cdiv(R, 4)), block(256);
 #define LN_CASE(NV)                                                                                              \
-    hipLaunchKernelGGL((ln_modulate_kernel<NV, TM, TO>), grid, block, 0, st, x, ldx, (const TM*)shift,           \
-                       (const TM*)scale, ldmod, (TO*)y, ldy, mean, rstd, R, H)
+    do {                                                                                                         \
+        if (sp)                                                                                                  \
+            hipLaunchKernelGGL((ln_modulate_kernel<NV, TM, TO, true>), grid, block, 0, st, x, ldx, (const TM*)shift, \
+                               (const TM*)scale, ldmod, (TO*)y, ldy, mean, rstd, R, H, *sp);                     \
+        else                                                                                                     \
+            hipLaunchKernelGGL((ln_modulate_kernel<NV, TM, TO, false>), grid, block, 0, st, x, ldx, (const TM*)shift, \
+                               (const TM*)scale, ldmod, (TO*)y, ldy, mean, rstd, R, H, LnSplit{});               \
+    } while (0)
     if (H <= 256) LN_CASE(1);
     else if (H <= 512) LN_CASE(2);
     else if (H <= 1024) LN_CASE(4);
@@ -201,6 +233,32 @@ extern "C" int stdiff_ln_modulate(const float* x, int ldx, const void* shift, co
     if (!mb && !ob) return launch_ln<float, float>(x, ldx, shift, scale, ldmod, y, ldy, mean, rstd, R, H, st);
     if (!mb && ob) return launch_ln<float, bf16_t>(x, ldx, shift, scale, ldmod, y, ldy, mean, rstd, R, H, st);
     return launch_ln<bf16_t, float>(x, ldx, shift, scale, ldmod, y, ldy, mean, rstd, R, H, st);
+}
+
+extern "C" int stdiff_ln_modulate_split(const stdiff_split_result* sp, const float* bias, const void* gate, int ldgate,
+                                        const float* res, int ldres, float* x, int ldx, void* v_out, int ldv,
+                                        const void* shift, const void* scale, int ldmod, int mod_dtype, void* y, int ldy,
+                                        int out_dtype, float* mean, float* rstd, int R, int H, void* stream) {
+    STDIFF_CHECK_ARG(sp && sp->ws && sp->slices >= 1 && sp->slices <= STDIFF_MAX_SLICES && sp->ldws >= H && x && shift && scale && y && R >= 0 && H > 0);
+    STDIFF_CHECK_ARG((mean == nullptr) == (rstd == nullptr) && (gate == nullptr) == (res == nullptr));
+    STDIFF_CHECK_ARG(mod_dtype == STDIFF_F32 || mod_dtype == STDIFF_BF16);
+    if (R == 0) return STDIFF_OK;
+    if (H % 4) return STDIFF_ERR_SHAPE;
+    const bool mb = mod_dtype == STDIFF_BF16, ob = out_dtype == STDIFF_BF16;
+    auto ok_mod = [&](const void* q) { return (((uintptr_t)q) & (mb ? 7 : 15)) == 0; };
+    if (ldx % 4 || ldmod % 4 || ldy % 4 || sp->ldws % 4 || sp->slice_stride % 4 || !al16(sp->ws) || !al16(x) ||
+        !ok_mod(shift) || !ok_mod(scale) || ((uintptr_t)y & 7) || (bias && !al16(bias)) ||
+        (gate && (ldgate % 4 || ldres % 4 || !ok_mod(gate) || !al16(res))) || (v_out && (ldv % 4 || !ok_mod(v_out))))
+        return STDIFF_ERR_ALIGN;
+    LnSplit q;
+    q.ws = sp->ws; q.ldws = sp->ldws; q.slices = sp->slices; q.stride = sp->slice_stride;
+    q.bias = bias; q.gate = gate; q.ldgate = ldgate; q.res = res; q.ldres = ldres;
+    q.x_out = x; q.ldxo = ldx; q.v_out = v_out; q.ldv = ldv;
+    hipStream_t st = (hipStream_t)stream;
+    if (mb && ob) return launch_ln<bf16_t, bf16_t>(x, ldx, shift, scale, ldmod, y, ldy, mean, rstd, R, H, st, &q);
+    if (!mb && !ob) return launch_ln<float, float>(x, ldx, shift, scale, ldmod, y, ldy, mean, rstd, R, H, st, &q);
+    if (!mb && ob) return launch_ln<float, bf16_t>(x, ldx, shift, scale, ldmod, y, ldy, mean, rstd, R, H, st, &q);
+    return launch_ln<bf16_t, float>(x, ldx, shift, scale, ldmod, y, ldy, mean, rstd, R, H, st, &q);
 }
 
 extern "C" int stdiff_row_stats(const float* x, int ldx, float* parts, int R, int H, void* stream) {

@@ -13,13 +13,16 @@ template <typename T> __device__ __forceinline__ float ldf(const void* p, size_t
 
 // ---------------------------------------------------------------- LayerNorm-modulate backward, one wave per row
 // y = xhat*(1+scale)+shift, xhat = (x-mean)*rstd:  g = dy*(1+scale);  dx = rstd*(g - mean(g) - xhat*mean(g*xhat))
-template <int NV, typename T>
+// SPLIT: dy is not read but summed from split-K partial products (stdiff_split_result) and rounded to T, which is what
+// the reduce launch it replaces would have stored.
+template <int NV, typename T, bool SPLIT = false>
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const T* dy, int lddy, const float* x, int ldx,
                                                          const float* mean, const float* rstd, const T* scale,
                                                          int ldmod, float* dx, int lddx, int accumulate, T* dshift,
                                                          T* dscale, int lddmod, int R, int H, const T* gate,
                                                          int ldgate, const T* branch, int ldbr, T* dbranch, int lddb,
-                                                         T* dgate, int lddg) {
+                                                         T* dgate, int lddg, const float* ws, int ldws, int slices,
+                                                         long long stride) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= R) return;
@@ -30,8 +33,18 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const T* dy, int lddy, 
     for (int i = 0; i < NV; ++i) {
         int c = (i * 64 + lane) * 4;
         if (c < H) {
-            f32x4 d = ld4(dy + (size_t)row * lddy + c), xv = *(const f32x4*)(x + (size_t)row * ldx + c),
-                  sc = ld4(scale + (size_t)row * ldmod + c), ds;
+            f32x4 d;
+            if constexpr (SPLIT) {
+                const float* w = ws + (size_t)row * ldws + c;
+                d = sum_slices(w, slices, stride);
+                if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d[j] = bf2f(f2bf(d[j]));
+                }
+            } else {
+                d = ld4(dy + (size_t)row * lddy + c);
+            }
+            f32x4 xv = *(const f32x4*)(x + (size_t)row * ldx + c), sc = ld4(scale + (size_t)row * ldmod + c), ds;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 xh[i][j] = (xv[j] - mu) * rs;
@@ -262,12 +275,22 @@ template <typename T>
 int launch_ln_bwd(const void* dy, int lddy, const float* x, int ldx, const float* mean, const float* rstd,
                   const void* scale, int ldmod, float* dx, int lddx, int acc, void* dshift, void* dscale, int lddmod,
                   int R, int H, hipStream_t st, const void* gate = nullptr, int ldgate = 0, const void* branch = nullptr,
-                  int ldbr = 0, void* dbranch = nullptr, int lddb = 0, void* dgate = nullptr, int lddg = 0) {
+                  int ldbr = 0, void* dbranch = nullptr, int lddb = 0, void* dgate = nullptr, int lddg = 0,
+                  const stdiff_split_result* sp = nullptr) {
     dim3 grid(cdiv(R, 4)), block(256);
 #define CASE(NV)                                                                                                   \
-    hipLaunchKernelGGL((ln_mod_bwd_kernel<NV, T>), grid, block, 0, st, (const T*)dy, lddy, x, ldx, mean, rstd,     \
-                       (const T*)scale, ldmod, dx, lddx, acc, (T*)dshift, (T*)dscale, lddmod, R, H, (const T*)gate,   \
-                       ldgate, (const T*)branch, ldbr, (T*)dbranch, lddb, (T*)dgate, lddg)
+    do {                                                                                                           \
+        if (sp)                                                                                                    \
+            hipLaunchKernelGGL((ln_mod_bwd_kernel<NV, T, true>), grid, block, 0, st, (const T*)nullptr, 0, x, ldx, mean,   \
+                               rstd, (const T*)scale, ldmod, dx, lddx, acc, (T*)dshift, (T*)dscale, lddmod, R, H,  \
+                               (const T*)gate, ldgate, (const T*)branch, ldbr, (T*)dbranch, lddb, (T*)dgate, lddg, \
+                               sp->ws, sp->ldws, sp->slices, sp->slice_stride);                                    \
+        else                                                                                                       \
+            hipLaunchKernelGGL((ln_mod_bwd_kernel<NV, T, false>), grid, block, 0, st, (const T*)dy, lddy, x, ldx, mean,    \
+                               rstd, (const T*)scale, ldmod, dx, lddx, acc, (T*)dshift, (T*)dscale, lddmod, R, H,  \
+                               (const T*)gate, ldgate, (const T*)branch, ldbr, (T*)dbranch, lddb, (T*)dgate, lddg, \
+                               (const float*)nullptr, 0, 0, 0ll);                                                  \
+    } while (0)
     if (H <= 256) CASE(1);
     else if (H <= 512) CASE(2);
     else if (H <= 1024) CASE(4);
@@ -321,6 +344,32 @@ extern "C" int stdiff_ln_modulate_bwd_gate(const void* dy, int lddy, int dtype, 
                                      lddmod, R, H, (hipStream_t)stream, gate, ldgate, branch, ldbr, dbranch, lddb, dgate, lddg);
     return launch_ln_bwd<float>(dy, lddy, x, ldx, mean, rstd, scale, ldmod, dx, lddx, accumulate, dshift, dscale,
                                 lddmod, R, H, (hipStream_t)stream, gate, ldgate, branch, ldbr, dbranch, lddb, dgate, lddg);
+}
+
+extern "C" int stdiff_ln_modulate_bwd_split(const stdiff_split_result* sp, int dtype, const float* x, int ldx,
+                                            const float* mean, const float* rstd, const void* scale, int ldmod, float* dx,
+                                            int lddx, int accumulate, void* dshift, void* dscale, int lddmod,
+                                            const void* gate, int ldgate, const void* branch, int ldbr, void* dbranch,
+                                            int lddb, void* dgate, int lddg, int R, int H, void* stream) {
+    STDIFF_CHECK_ARG(sp && sp->ws && sp->slices >= 1 && sp->slices <= STDIFF_MAX_SLICES && sp->ldws >= H);
+    STDIFF_CHECK_ARG(x && mean && rstd && scale && dx && dshift && dscale && R >= 0 && H > 0);
+    STDIFF_CHECK_ARG(gate ? (branch && dbranch && dgate) : (!branch && !dbranch && !dgate));
+    STDIFF_CHECK_ARG(dtype == STDIFF_F32 || dtype == STDIFF_BF16);
+    if (R == 0) return STDIFF_OK;
+    if (H % 4) return STDIFF_ERR_SHAPE;
+    const bool bf = dtype == STDIFF_BF16;
+    auto ok = [&](const void* q) { return bf ? al8(q) : al16(q); };
+    if (sp->ldws % 4 || sp->slice_stride % 4 || !al16(sp->ws) || ldx % 4 || ldmod % 4 || lddx % 4 || lddmod % 4 ||
+        !al16(x) || !al16(dx) || !ok(scale) || !ok(dshift) || !ok(dscale))
+        return STDIFF_ERR_ALIGN;
+    if (gate && (ldgate % 4 || ldbr % 4 || lddb % 4 || lddg % 4 || !ok(gate) || !ok(branch) || !ok(dbranch) || !ok(dgate)))
+        return STDIFF_ERR_ALIGN;
+    if (bf)
+        return launch_ln_bwd<bf16_t>(nullptr, 0, x, ldx, mean, rstd, scale, ldmod, dx, lddx, accumulate, dshift, dscale,
+                                     lddmod, R, H, (hipStream_t)stream, gate, ldgate, branch, ldbr, dbranch, lddb, dgate,
+                                     lddg, sp);
+    return launch_ln_bwd<float>(nullptr, 0, x, ldx, mean, rstd, scale, ldmod, dx, lddx, accumulate, dshift, dscale, lddmod,
+                                R, H, (hipStream_t)stream, gate, ldgate, branch, ldbr, dbranch, lddb, dgate, lddg, sp);
 }
 
 extern "C" int stdiff_gate_bwd(const float* dh, int lddh, const void* gate, int ldgate, const void* branch, int ldbr,

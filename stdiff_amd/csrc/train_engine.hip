@@ -67,8 +67,10 @@ struct Ctx {
     // C[M,N] = epi(A[M,K] W[N,K]^T + b), everything row-major
     int lin(bool on_side, int M, int N, int K, const void* A, int lda, const stdiff_train_linear& l, int ldw, void* C,
             int ldc, int cdt, int epi = STDIFF_EPI_BIAS, const void* gate = nullptr, int ldgate = 0,
-            const float* res = nullptr, int ldres = 0, void* C2 = nullptr, int ldc2 = 0) const {
+            const float* res = nullptr, int ldres = 0, void* C2 = nullptr, int ldc2 = 0,
+            stdiff_split_result* defer = nullptr) const {
         stdiff_gemm_args g = {};
+        g.defer = a->no_defer ? nullptr : defer;
         g.M = M; g.N = N; g.K = K; g.A = A; g.lda = lda; g.a_dtype = w->dtype; g.W = l.w; g.ldw = ldw; g.bias = l.b;
         g.C = C; g.ldc = ldc; g.c_dtype = cdt; g.epi = epi; g.gate = gate; g.ldgate = ldgate; g.res = res; g.ldres = ldres;
         g.C2 = C2; g.ldc2 = ldc2; g.workspace = ws(on_side); g.workspace_bytes = ws_bytes(on_side);
@@ -76,8 +78,10 @@ struct Ctx {
     }
     // out[M, n_in] (+)= dY[M, k_pad] W, W = [k_valid rows (out features)][n_in] read K-major
     int dX(bool on_side, int M, const void* dY, int lddy, int k_pad, const stdiff_train_linear& l, int k_valid, int n_in,
-           void* out, int ldo, int odt, int epi = STDIFF_EPI_BIAS, const void* side_in = nullptr, int ldside = 0) const {
+           void* out, int ldo, int odt, int epi = STDIFF_EPI_BIAS, const void* side_in = nullptr, int ldside = 0,
+           stdiff_split_result* defer = nullptr) const {
         stdiff_gemm_args g = {};
+        g.defer = a->no_defer ? nullptr : defer;
         g.gate = side_in; g.ldgate = ldside;
         g.M = M; g.N = n_in; g.K = k_pad; g.A = dY; g.lda = lddy; g.a_dtype = w->dtype; g.W = l.w; g.ldw = n_in;
         g.C = out; g.ldc = ldo; g.c_dtype = odt; g.epi = epi; g.w_layout = STDIFF_K_MAJOR; g.k_valid = k_valid;
@@ -166,6 +170,35 @@ struct Ctx {
         if (forking && have_prev) TRYH(hipStreamWaitEvent(main, ev[1 + (done_i ^ 1)], 0));
         return STDIFF_OK;
     }
+    // A residual-stream tensor whose producing GEMM may have left it as split-K partial products (stdiff_gemm's defer):
+    // the LayerNorm that consumes it then sums the slices and applies the producer's bias / gated residual itself.
+    struct Pend {
+        stdiff_split_result sp = {};
+        const float* bias = nullptr; const void* gate = nullptr; int ldgate = 0; const float* res = nullptr; int ldres = 0;
+        void* v = nullptr; int ldv = 0;
+    };
+    int ln(const Pend& pd, float* x, int ldx, const void* shift, const void* scale, int ldmod, void* y, float* mean,
+           float* rstd) const {
+        const int dt = w->dtype, H = w->H;
+        if (pd.sp.slices > 1)
+            return stdiff_ln_modulate_split(&pd.sp, pd.bias, pd.gate, pd.ldgate, pd.res, pd.ldres, x, ldx, pd.v, pd.ldv,
+                                            shift, scale, ldmod, dt, y, H, dt, mean, rstd, a->C, H, main);
+        return stdiff_ln_modulate(x, ldx, shift, scale, ldmod, dt, y, H, dt, mean, rstd, a->C, H, main);
+    }
+    // LayerNorm backward (+ the gate product of the branch below when `gate` is given) of a dy that may be deferred
+    int ln_bwd(const stdiff_split_result& sp, const void* dy, const float* x, const float* mean, const float* rstd,
+               const void* scale, int ldmod, int accumulate, void* dshift, void* dscale, int lddmod, const void* gate,
+               int ldgate, const void* branch, void* dbranch, void* dgate, int lddg) const {
+        const int dt = w->dtype, H = w->H, C = a->C;
+        if (sp.slices > 1)
+            return stdiff_ln_modulate_bwd_split(&sp, dt, x, H, mean, rstd, scale, ldmod, a->dh, H, accumulate, dshift, dscale,
+                                                lddmod, gate, ldgate, branch, H, dbranch, H, dgate, lddg, C, H, main);
+        if (gate)
+            return stdiff_ln_modulate_bwd_gate(dy, H, dt, x, H, mean, rstd, scale, ldmod, a->dh, H, accumulate, dshift,
+                                               dscale, lddmod, gate, ldgate, branch, H, dbranch, H, dgate, lddg, C, H, main);
+        return stdiff_ln_modulate_bwd(dy, H, dt, x, H, mean, rstd, scale, ldmod, a->dh, H, accumulate, dshift, dscale,
+                                      lddmod, C, H, main);
+    }
 };
 
 int check_common(const stdiff_train_weights* w, const stdiff_train_acts* a) {
@@ -194,16 +227,19 @@ int backward_grouped(Ctx& c, stdiff_bucket_fn after_bucket, void* user) {
     const bool odd_genes = G % 8 != 0;          // in / cond / out layer: no 16-byte column pieces -> the one-job path
     // ---- final layer (FinalLayer.forward, stDiff_model.py:135-141)
     if (odd_genes) TRY(c.dW(w->out, G, H, a->deps, Gp, Gp, a->xnf, H, H));
-    TRY(c.dX(false, C, a->deps, Gp, Gp, w->out, G, H, a->dxn, H, dt));
+    // every input-gradient GEMM whose consumer is the next launch on this stream may leave its result as split-K partial
+    // products (`sp`): the consumer sums them (stdiff_*_split) and the reduce launch disappears from the chain
+    stdiff_split_result sp = {};
+    TRY(c.dX(false, C, a->deps, Gp, Gp, w->out, G, H, a->dxn, H, dt, STDIFF_EPI_BIAS, nullptr, 0, &sp));
     if (D > 0) {
         const stdiff_train_block_acts& sl = a->blocks[D - 1];
         const int ql = (D - 1) & 1;
-        TRY(stdiff_ln_modulate_bwd_gate(a->dxn, H, dt, a->h_last, H, a->meanf, a->rstdf, col(a->fmod, dt, H), 2 * H, a->dh,
-                                        H, 0, col(a->dfmod, dt, 0), col(a->dfmod, dt, H), 2 * H, col(sl.mod, dt, 5 * H),
-                                        6 * H, sl.pm, H, dbrm[ql], H, col(a->dmod[ql], dt, 5 * H), 6 * H, C, H, stream));
+        TRY(c.ln_bwd(sp, a->dxn, a->h_last, a->meanf, a->rstdf, col(a->fmod, dt, H), 2 * H, 0, col(a->dfmod, dt, 0),
+                     col(a->dfmod, dt, H), 2 * H, col(sl.mod, dt, 5 * H), 6 * H, sl.pm, dbrm[ql],
+                     col(a->dmod[ql], dt, 5 * H), 6 * H));
     } else {
-        TRY(stdiff_ln_modulate_bwd(a->dxn, H, dt, a->h_last, H, a->meanf, a->rstdf, col(a->fmod, dt, H), 2 * H, a->dh, H,
-                                   0, col(a->dfmod, dt, 0), col(a->dfmod, dt, H), 2 * H, C, H, stream));
+        TRY(c.ln_bwd(sp, a->dxn, a->h_last, a->meanf, a->rstdf, col(a->fmod, dt, H), 2 * H, 0, col(a->dfmod, dt, 0),
+                     col(a->dfmod, dt, H), 2 * H, nullptr, 0, nullptr, nullptr, nullptr, 0));
     }
     {
         stdiff_dw_group_args g = {};
@@ -222,26 +258,28 @@ int backward_grouped(Ctx& c, stdiff_bucket_fn after_bucket, void* user) {
         void* dmod = a->dmod[q];
         // MLP branch (DiTblock.forward, stDiff_model.py:116); GELU backward in the fc2 dX epilogue
         TRY(c.dX(false, C, dbrm[q], H, H, b.fc2, H, 4 * H, dupre[q], 4 * H, dt, STDIFF_EPI_GELU_BWD, s.upre, 4 * H));
-        TRY(c.dX(false, C, dupre[q], 4 * H, 4 * H, b.fc1, 4 * H, H, a->dxn, H, dt));
+        TRY(c.dX(false, C, dupre[q], 4 * H, 4 * H, b.fc1, 4 * H, H, a->dxn, H, dt, STDIFF_EPI_BIAS, nullptr, 0, &sp));
         // LayerNorm 2 backward + the attention branch's gate (:114)
-        TRY(stdiff_ln_modulate_bwd_gate(a->dxn, H, dt, s.hmid, H, s.mean2, s.rstd2, col(s.mod, dt, 4 * H), 6 * H, a->dh, H, 1,
-                                        col(dmod, dt, 3 * H), col(dmod, dt, 4 * H), 6 * H, col(s.mod, dt, 2 * H), 6 * H, s.pa,
-                                        H, dbra[q], H, col(dmod, dt, 2 * H), 6 * H, C, H, stream));
-        TRY(c.dX(false, C, dbra[q], H, H, b.proj, H, H, a->do_, H, dt));
-        TRY(stdiff_attention_bwd(s.qkv, 3 * H, s.o, H, a->do_, H, s.lse, a->delta, dqkv[q], 3 * H, a->cu_rows, 1, C, C,
-                                 w->heads, d, dt, stream));
-        TRY(c.dX(false, C, dqkv[q], 3 * H, 3 * H, b.qkv, 3 * H, H, a->dxn, H, dt));
+        TRY(c.ln_bwd(sp, a->dxn, s.hmid, s.mean2, s.rstd2, col(s.mod, dt, 4 * H), 6 * H, 1, col(dmod, dt, 3 * H),
+                     col(dmod, dt, 4 * H), 6 * H, col(s.mod, dt, 2 * H), 6 * H, s.pa, dbra[q], col(dmod, dt, 2 * H), 6 * H));
+        TRY(c.dX(false, C, dbra[q], H, H, b.proj, H, H, a->do_, H, dt, STDIFF_EPI_BIAS, nullptr, 0, &sp));
+        if (sp.slices > 1)
+            TRY(stdiff_attention_bwd_split(s.qkv, 3 * H, s.o, H, &sp, a->do_, H, s.lse, a->delta, dqkv[q], 3 * H, a->cu_rows,
+                                           1, C, C, w->heads, d, dt, stream));
+        else
+            TRY(stdiff_attention_bwd(s.qkv, 3 * H, s.o, H, a->do_, H, s.lse, a->delta, dqkv[q], 3 * H, a->cu_rows, 1, C, C,
+                                     w->heads, d, dt, stream));
+        TRY(c.dX(false, C, dqkv[q], 3 * H, 3 * H, b.qkv, 3 * H, H, a->dxn, H, dt, STDIFF_EPI_BIAS, nullptr, 0, &sp));
         // the group forked a block ago (block k + 1, or the final layer's) has read the buffers of the other parity
         TRY(c.join());
         if (after_bucket) after_bucket(D - 1 - k, user);
         if (k > 0) {        // LayerNorm 1 backward + the MLP gate of the block below (the other parity's buffers)
             const stdiff_train_block_acts& sb = a->blocks[k - 1];
-            TRY(stdiff_ln_modulate_bwd_gate(a->dxn, H, dt, s.h, H, s.mean1, s.rstd1, col(s.mod, dt, H), 6 * H, a->dh, H, 1,
-                                            col(dmod, dt, 0), col(dmod, dt, H), 6 * H, col(sb.mod, dt, 5 * H), 6 * H, sb.pm,
-                                            H, dbrm[q ^ 1], H, col(a->dmod[q ^ 1], dt, 5 * H), 6 * H, C, H, stream));
+            TRY(c.ln_bwd(sp, a->dxn, s.h, s.mean1, s.rstd1, col(s.mod, dt, H), 6 * H, 1, col(dmod, dt, 0), col(dmod, dt, H),
+                         6 * H, col(sb.mod, dt, 5 * H), 6 * H, sb.pm, dbrm[q ^ 1], col(a->dmod[q ^ 1], dt, 5 * H), 6 * H));
         } else {
-            TRY(stdiff_ln_modulate_bwd(a->dxn, H, dt, s.h, H, s.mean1, s.rstd1, col(s.mod, dt, H), 6 * H, a->dh, H, 1,
-                                       col(dmod, dt, 0), col(dmod, dt, H), 6 * H, C, H, stream));
+            TRY(c.ln_bwd(sp, a->dxn, s.h, s.mean1, s.rstd1, col(s.mod, dt, H), 6 * H, 1, col(dmod, dt, 0), col(dmod, dt, H),
+                         6 * H, nullptr, 0, nullptr, nullptr, nullptr, 0));
         }
         stdiff_dw_group_args g = {};
         g.C = C; g.dtype = dt;
@@ -314,7 +352,14 @@ extern "C" int stdiff_dit_train_forward(const stdiff_train_weights* w, const std
             TRYH(hipEventRecord(c.ev[3 + k], c.side));
         }
     }
-    TRY(c.lin(false, C, H, Gp, a->xp, Gp, w->in, Gp, D ? a->blocks[0].h : a->h_last, H, STDIFF_F32));
+    // `pend`: the block input may still lie as split-K partial products of the GEMM that produces it (in_layer, then
+    // each block's fc2): the LayerNorm that reads it first sums them (one launch less on the chain per deferral)
+    // (only with the side stream: without it the block's adaLN GEMM sits between producer and consumer on this stream
+    // and may use the same split-K workspace)
+    Ctx::Pend pend;
+    pend.bias = w->in.b;
+    TRY(c.lin(false, C, H, Gp, a->xp, Gp, w->in, Gp, D ? a->blocks[0].h : a->h_last, H, STDIFF_F32, STDIFF_EPI_BIAS, nullptr,
+              0, nullptr, 0, nullptr, 0, fork ? &pend.sp : nullptr));
     for (int k = 0; k < D; ++k) {
         const stdiff_train_block& b = w->blocks[k];
         const stdiff_train_block_acts& s = a->blocks[k];
@@ -323,23 +368,26 @@ extern "C" int stdiff_dit_train_forward(const stdiff_train_weights* w, const std
                          s.u && s.mean1 && s.rstd1 && s.mean2 && s.rstd2);
         if (fork) TRYH(hipStreamWaitEvent(c.main, c.ev[3 + k], 0));
         else TRY(c.lin(false, C, 6 * H, H, a->s, H, b.ada, H, s.mod, 6 * H, dt));
-        TRY(stdiff_ln_modulate(s.h, H, col(s.mod, dt, 0), col(s.mod, dt, H), 6 * H, dt, s.xn1, H, dt, s.mean1, s.rstd1, C,
-                               H, stream));
+        TRY(c.ln(pend, s.h, H, col(s.mod, dt, 0), col(s.mod, dt, H), 6 * H, s.xn1, s.mean1, s.rstd1));
         TRY(c.lin(false, C, 3 * H, H, s.xn1, H, b.qkv, H, s.qkv, 3 * H, dt));
         TRY(stdiff_attention_fwd(s.qkv, 3 * H, s.o, H, s.lse, a->cu_rows, 1, C, w->heads, d, dt, stream));
+        Ctx::Pend mid;
+        mid.bias = b.proj.b; mid.gate = col(s.mod, dt, 2 * H); mid.ldgate = 6 * H; mid.res = s.h; mid.ldres = H;
+        mid.v = s.pa; mid.ldv = H;
         TRY(c.lin(false, C, H, H, s.o, H, b.proj, H, s.hmid, H, STDIFF_F32, STDIFF_EPI_GATE_RES, col(s.mod, dt, 2 * H),
-                  6 * H, s.h, H, s.pa, H));
-        TRY(stdiff_ln_modulate(s.hmid, H, col(s.mod, dt, 3 * H), col(s.mod, dt, 4 * H), 6 * H, dt, s.xn2, H, dt, s.mean2,
-                               s.rstd2, C, H, stream));
+                  6 * H, s.h, H, s.pa, H, &mid.sp));
+        TRY(c.ln(mid, s.hmid, H, col(s.mod, dt, 3 * H), col(s.mod, dt, 4 * H), 6 * H, s.xn2, s.mean2, s.rstd2));
         TRY(c.lin(false, C, 4 * H, H, s.xn2, H, b.fc1, H, s.u, 4 * H, dt, STDIFF_EPI_GELU_SAVE, nullptr, 0, nullptr, 0,
                   s.upre, 4 * H));
+        pend = Ctx::Pend();
+        pend.bias = b.fc2.b; pend.gate = col(s.mod, dt, 5 * H); pend.ldgate = 6 * H; pend.res = s.hmid; pend.ldres = H;
+        pend.v = s.pm; pend.ldv = H;
         TRY(c.lin(false, C, H, 4 * H, s.u, 4 * H, b.fc2, 4 * H, h_next, H, STDIFF_F32, STDIFF_EPI_GATE_RES,
-                  col(s.mod, dt, 5 * H), 6 * H, s.hmid, H, s.pm, H));
+                  col(s.mod, dt, 5 * H), 6 * H, s.hmid, H, s.pm, H, fork ? &pend.sp : nullptr));
     }
     if (fork) TRYH(hipStreamWaitEvent(c.main, c.ev[3 + D], 0));
     else TRY(c.lin(false, C, 2 * H, H, a->s, H, w->fada, H, a->fmod, 2 * H, dt));
-    TRY(stdiff_ln_modulate(a->h_last, H, col(a->fmod, dt, 0), col(a->fmod, dt, H), 2 * H, dt, a->xnf, H, dt, a->meanf,
-                           a->rstdf, C, H, stream));
+    TRY(c.ln(pend, a->h_last, H, col(a->fmod, dt, 0), col(a->fmod, dt, H), 2 * H, a->xnf, a->meanf, a->rstdf));
     return c.lin(false, C, G, H, a->xnf, H, w->out, H, a->eps, G, STDIFF_F32);
 }
 

@@ -13,11 +13,14 @@ def round_up(a, b):
 
 
 def gemm(A, W, bias=None, out=None, out_dtype=None, epi=L.EPI_BIAS, gate=None, res=None, out2=None, M=None,
-         workspace=None, a_kmajor=False, w_kmajor=False, static_scratch=False, ln_parts=None, stats_out=None):
+         workspace=None, a_kmajor=False, w_kmajor=False, static_scratch=False, ln_parts=None, stats_out=None,
+         defer=None):
     """out[M,N] = epi(A[M,K] @ W[N,K]^T + bias). A/W: same dtype (fp32 or bf16), K-contiguous rows -- or, with
     a_kmajor / w_kmajor, given as [K, M] / [K, N] (K rows; need not be a multiple of the K-slab).
     static_scratch=True: stdiff_gemm_static_scratch -- split-K partials in the library's own device array, nothing is
-    allocated by the library (`out` must be given for the CALLER not to allocate either)."""
+    allocated by the library (`out` must be given for the CALLER not to allocate either).
+    defer: an L.SplitResult; when the launch splits K (bias / gated-residual epilogues only) the reduce launch is skipped
+    and `defer` describes the partial products for a *_split consumer (defer.slices == 0: `out` is complete)."""
     require_gpu(A, W, bias, out, gate, res, out2, workspace)
     bk = 64 if A.element_size() == 2 else 16
     kA = A.shape[0] if a_kmajor else A.shape[1]
@@ -60,6 +63,8 @@ def gemm(A, W, bias=None, out=None, out_dtype=None, epi=L.EPI_BIAS, gate=None, r
         a.stats_out = ptr(stats_out)
     if workspace is not None:          # fp32 scratch for split-K (small outputs with a long K)
         a.workspace, a.workspace_bytes = ptr(workspace), workspace.numel() * workspace.element_size()
+    if defer is not None:
+        a.defer = C.pointer(defer)
     lb = lib_for(A, W, out, gate, out2)
     check((lb.stdiff_gemm_static_scratch if static_scratch else lb.stdiff_gemm)(C.byref(a), stream()))
     return out
@@ -109,13 +114,23 @@ def attention_fwd(qkv, cu_rows, max_chunk, heads, out=None, lse=None):
     return out
 
 
-def ln_modulate(x, shift, scale, out=None, out_dtype=None, mean=None, rstd=None):
-    """LayerNorm(x, eps=1e-6, no affine) * (1 + scale) + shift; shift/scale are column views of the adaLN output."""
-    require_gpu(x, shift, scale, out)
+def ln_modulate(x, shift, scale, out=None, out_dtype=None, mean=None, rstd=None, split=None, bias=None, gate=None,
+                res=None, v_out=None):
+    """LayerNorm(x, eps=1e-6, no affine) * (1 + scale) + shift; shift/scale are column views of the adaLN output.
+    split (an L.SplitResult with slices > 1): x is not read but FORMED first -- v = sum of the slices + bias,
+    x = res + gate * v (x = v without a gate), v_out = v -- and written (stdiff_ln_modulate_split)."""
+    require_gpu(x, shift, scale, out, bias, gate, res, v_out)
     R, H = x.shape
     assert shift.stride(0) == scale.stride(0) and shift.dtype == scale.dtype
     if out is None:
         out = torch.empty((R, H), device=x.device, dtype=out_dtype or shift.dtype)
+    if split is not None and split.slices > 1:
+        check(lib_for(shift, out).stdiff_ln_modulate_split(
+            C.byref(split), ptr(bias), ptr(gate), gate.stride(0) if gate is not None else 0, ptr(res),
+            res.stride(0) if res is not None else 0, ptr(x), x.stride(0), ptr(v_out),
+            v_out.stride(0) if v_out is not None else 0, ptr(shift), ptr(scale), shift.stride(0), dt_of(shift), ptr(out),
+            out.stride(0), dt_of(out), ptr(mean), ptr(rstd), R, H, stream()))
+        return out
     check(lib_for(shift, out).stdiff_ln_modulate(ptr(x), x.stride(0), ptr(shift), ptr(scale), shift.stride(0), dt_of(shift),
                                    ptr(out), out.stride(0), dt_of(out), ptr(mean), ptr(rstd), R, H, stream()))
     return out
@@ -219,7 +234,8 @@ def masked_mse(pred, noise, mask, loss, dpred=None, dp=None, grad_scale=1.0):
                                   grad_scale, pred.shape[0], pred.shape[1], stream()))
 
 
-def attention_bwd(qkv, out, dout, lse, cu_rows, max_chunk, heads, dqkv=None, delta=None):
+def attention_bwd(qkv, out, dout, lse, cu_rows, max_chunk, heads, dqkv=None, delta=None, split=None):
+    """split (an L.SplitResult with slices > 1): dout is first FORMED from the partial products (and written)."""
     require_gpu(qkv, out, dout, lse, cu_rows, dqkv, delta)
     R, H3 = qkv.shape
     H = H3 // 3
@@ -227,6 +243,12 @@ def attention_bwd(qkv, out, dout, lse, cu_rows, max_chunk, heads, dqkv=None, del
         dqkv = torch.empty_like(qkv)
     if delta is None:
         delta = torch.empty((R, heads), device=qkv.device, dtype=torch.float32)
+    if split is not None and split.slices > 1:
+        check(lib_for(qkv, out, dout, dqkv).stdiff_attention_bwd_split(
+            ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), C.byref(split), ptr(dout), dout.stride(0), ptr(lse),
+            ptr(delta), ptr(dqkv), dqkv.stride(0), ptr(cu_rows), cu_rows.numel() - 1, max_chunk, R, heads, H // heads,
+            dt_of(qkv), stream()))
+        return dqkv
     check(lib_for(qkv, out, dout, dqkv).stdiff_attention_bwd(ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(dout), dout.stride(0),
                                      ptr(lse), ptr(delta), ptr(dqkv), dqkv.stride(0), ptr(cu_rows),
                                      cu_rows.numel() - 1, max_chunk, R, heads, H // heads, dt_of(qkv), stream()))
@@ -234,13 +256,20 @@ def attention_bwd(qkv, out, dout, lse, cu_rows, max_chunk, heads, dqkv=None, del
 
 
 def ln_modulate_bwd(dy, x, mean, rstd, scale, dx, dshift, dscale, accumulate=True, gate=None, branch=None, dbranch=None,
-                    dgate=None):
+                    dgate=None, split=None):
     """LayerNorm + modulate backward; with gate / branch / dbranch / dgate also the gated-residual backward of the
     branch below it on the finished dx row (dbranch = dx * gate, dgate = dx * branch): one launch instead of two."""
     require_gpu(dy, x, mean, rstd, scale, dx, dshift, dscale, gate, branch, dbranch, dgate)
     R, H = x.shape
     assert dshift.stride(0) == dscale.stride(0)
     lb = lib_for(dy, scale, dshift)
+    if split is not None and split.slices > 1:       # dy = the partial products summed (and rounded to the dtype)
+        z = lambda t_: t_.stride(0) if t_ is not None else 0
+        check(lb.stdiff_ln_modulate_bwd_split(C.byref(split), dt_of(scale), ptr(x), x.stride(0), ptr(mean), ptr(rstd),
+                                              ptr(scale), scale.stride(0), ptr(dx), dx.stride(0), int(accumulate),
+                                              ptr(dshift), ptr(dscale), dshift.stride(0), ptr(gate), z(gate), ptr(branch),
+                                              z(branch), ptr(dbranch), z(dbranch), ptr(dgate), z(dgate), R, H, stream()))
+        return
     if gate is None:
         check(lb.stdiff_ln_modulate_bwd(ptr(dy), dy.stride(0), dt_of(dy), ptr(x), x.stride(0), ptr(mean), ptr(rstd),
                                         ptr(scale), scale.stride(0), ptr(dx), dx.stride(0), int(accumulate),

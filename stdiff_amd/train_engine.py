@@ -100,6 +100,10 @@ class TrainCore:
         # one stdiff_dw_group launch per block for its five weight/bias gradients (STDIFF_TRAIN_GROUPED=0: one job of
         # three launches per linear layer, the older path, kept for A/B timing and as a second implementation)
         self.grouped = os.environ.get("STDIFF_TRAIN_GROUPED", "1") != "0"
+        # a split-K GEMM whose consumer is the next launch leaves its partial products to that consumer (LayerNorm
+        # forward / backward, attention backward) instead of paying a reduce launch (STDIFF_TRAIN_DEFER=0: A/B timing;
+        # results are bit-identical either way)
+        self.defer = os.environ.get("STDIFF_TRAIN_DEFER", "1") != "0"
         self._cw = None
 
     def refresh_weights(self, pack=True):
@@ -226,6 +230,7 @@ class TrainCore:
                 for i in range(3):
                     ca.dbr_b[i] = p(a["dbr_b"][i])
                 ca.dqkv_b = p(a["dqkv_b"])
+            ca.no_defer = 0 if self.defer else 1
             ca.splitk_ws, ca.splitk_bytes = p(self.ws_splitk), self.ws_splitk.numel() * 4
             a["_c"] = ca = (ca, blocks)
         ca = ca[0]
@@ -275,8 +280,13 @@ class TrainCore:
                     ev.record(self._side)
                     mod_ready.append(ev)
             self._side_on = False
+        # deferred split-K results (csrc/train_engine.hip, Ctx::Pend): the block input only with the side stream (else
+        # the block's adaLN GEMM sits between producer and consumer and may use the same split-K scratch)
+        def sr(on=True):
+            return L.SplitResult() if (self.defer and on) else None
         w, b = self._lin("in_layer.0")
-        g(a["xp"], w, b, out=a["h"][0])
+        pend = dict(split=sr(mod_ready is not None), bias=b)
+        g(a["xp"], w, b, out=a["h"][0], defer=pend["split"])
         for k in range(D):
             p = f"blks.{k}."
             mod = a["mod"][k]
@@ -285,24 +295,30 @@ class TrainCore:
                 g(a["s"], w, b, out=mod)
             else:
                 torch.cuda.current_stream().wait_event(mod_ready[k])
-            ops.ln_modulate(a["h"][k], mod[:, 0:H], mod[:, H:2 * H], out=a["xn1"][k], mean=a["mean1"][k], rstd=a["rstd1"][k])
+            ops.ln_modulate(a["h"][k], mod[:, 0:H], mod[:, H:2 * H], out=a["xn1"][k], mean=a["mean1"][k], rstd=a["rstd1"][k],
+                            **pend)
             w, b = self._lin(p + "attn.qkv")
             g(a["xn1"][k], w, b, out=a["qkv"][k])
             ops.attention_fwd(a["qkv"][k], a["cu"], a["C"], self.heads, out=a["o"][k], lse=a["lse"][k])
             w, b = self._lin(p + "attn.proj")
-            g(a["o"][k], w, b, out=a["hmid"][k], epi=L.EPI_GATE_RES, gate=mod[:, 2 * H:3 * H], res=a["h"][k], out2=a["pa"][k])
+            mid = dict(split=sr(), bias=b, gate=mod[:, 2 * H:3 * H], res=a["h"][k], v_out=a["pa"][k])
+            g(a["o"][k], w, b, out=a["hmid"][k], epi=L.EPI_GATE_RES, gate=mod[:, 2 * H:3 * H], res=a["h"][k], out2=a["pa"][k],
+              defer=mid["split"])
             ops.ln_modulate(a["hmid"][k], mod[:, 3 * H:4 * H], mod[:, 4 * H:5 * H], out=a["xn2"][k], mean=a["mean2"][k],
-                            rstd=a["rstd2"][k])
+                            rstd=a["rstd2"][k], **mid)
             w, b = self._lin(p + "mlp.fc1")
             g(a["xn2"][k], w, b, out=a["u"][k], epi=L.EPI_GELU_SAVE, out2=a["upre"][k])
             w, b = self._lin(p + "mlp.fc2")
-            g(a["u"][k], w, b, out=a["h"][k + 1], epi=L.EPI_GATE_RES, gate=mod[:, 5 * H:6 * H], res=a["hmid"][k], out2=a["pm"][k])
+            pend = dict(split=sr(mod_ready is not None), bias=b, gate=mod[:, 5 * H:6 * H], res=a["hmid"][k], v_out=a["pm"][k])
+            g(a["u"][k], w, b, out=a["h"][k + 1], epi=L.EPI_GATE_RES, gate=mod[:, 5 * H:6 * H], res=a["hmid"][k], out2=a["pm"][k],
+              defer=pend["split"])
         if mod_ready is None:
             w, b = self._lin("out_layer.adaLN_modulation.1")
             g(a["s"], w, b, out=a["fmod"])
         else:
             torch.cuda.current_stream().wait_event(mod_ready[D])
-        ops.ln_modulate(a["h"][D], a["fmod"][:, 0:H], a["fmod"][:, H:2 * H], out=a["xnf"], mean=a["meanf"], rstd=a["rstdf"])
+        ops.ln_modulate(a["h"][D], a["fmod"][:, 0:H], a["fmod"][:, H:2 * H], out=a["xnf"], mean=a["meanf"], rstd=a["rstdf"],
+                        **pend)
         w, b = self._lin("out_layer.linear")
         g(a["xnf"], w, b, out=a["eps"])
         return a["eps"]
@@ -382,16 +398,19 @@ class TrainCore:
         self._side_begin()
         if odd:
             self._dW(a, "out_layer.linear", deps, X=a["xnf"], rows=G)
-        self._dX("out_layer.linear", deps, a["dxn"])
+        def sr():
+            return L.SplitResult() if self.defer else None
+        sp = sr()
+        self._dX("out_layer.linear", deps, a["dxn"], defer=sp)
         if D > 0:
             ql = (D - 1) & 1
             ops.ln_modulate_bwd(a["dxn"], a["h"][D], a["meanf"], a["rstdf"], a["fmod"][:, H:2 * H], a["dh"],
                                 a["dfmod"][:, 0:H], a["dfmod"][:, H:2 * H], accumulate=False,
                                 gate=a["mod"][D - 1][:, 5 * H:6 * H], branch=a["pm"][D - 1], dbranch=dbrm[ql],
-                                dgate=a["dmod"][ql][:, 5 * H:6 * H])
+                                dgate=a["dmod"][ql][:, 5 * H:6 * H], split=sp)
         else:
             ops.ln_modulate_bwd(a["dxn"], a["h"][D], a["meanf"], a["rstdf"], a["fmod"][:, H:2 * H], a["dh"],
-                                a["dfmod"][:, 0:H], a["dfmod"][:, H:2 * H], accumulate=False)
+                                a["dfmod"][:, 0:H], a["dfmod"][:, H:2 * H], accumulate=False, split=sp)
         first = [("out_layer.adaLN_modulation.1", a["dfmod"], a["s"])]
         if not odd:
             first.append(("out_layer.linear", deps, a["xnf"], G))
@@ -400,14 +419,18 @@ class TrainCore:
             p, q = f"blks.{k}.", k & 1
             mod, dmod = a["mod"][k], a["dmod"][q]
             self._dX(p + "mlp.fc2", dbrm[q], dupre[q], epi=L.EPI_GELU_BWD, gate=a["upre"][k])
-            self._dX(p + "mlp.fc1", dupre[q], a["dxn"])
+            sp = sr()
+            self._dX(p + "mlp.fc1", dupre[q], a["dxn"], defer=sp)
             ops.ln_modulate_bwd(a["dxn"], a["hmid"][k], a["mean2"][k], a["rstd2"][k], mod[:, 4 * H:5 * H], a["dh"],
                                 dmod[:, 3 * H:4 * H], dmod[:, 4 * H:5 * H], accumulate=True,
-                                gate=mod[:, 2 * H:3 * H], branch=a["pa"][k], dbranch=dbra[q], dgate=dmod[:, 2 * H:3 * H])
-            self._dX(p + "attn.proj", dbra[q], a["do"])
+                                gate=mod[:, 2 * H:3 * H], branch=a["pa"][k], dbranch=dbra[q], dgate=dmod[:, 2 * H:3 * H],
+                                split=sp)
+            sp = sr()
+            self._dX(p + "attn.proj", dbra[q], a["do"], defer=sp)
             ops.attention_bwd(a["qkv"][k], a["o"][k], a["do"], a["lse"][k], a["cu"], a["C"], self.heads,
-                              dqkv=dqkv[q], delta=a["delta"])
-            self._dX(p + "attn.qkv", dqkv[q], a["dxn"])
+                              dqkv=dqkv[q], delta=a["delta"], split=sp)
+            sp = sr()
+            self._dX(p + "attn.qkv", dqkv[q], a["dxn"], defer=sp)
             self._side_join()
             if after_bucket:
                 after_bucket(D - 1 - k)
@@ -415,10 +438,10 @@ class TrainCore:
                 ops.ln_modulate_bwd(a["dxn"], a["h"][k], a["mean1"][k], a["rstd1"][k], mod[:, H:2 * H], a["dh"],
                                     dmod[:, 0:H], dmod[:, H:2 * H], accumulate=True,
                                     gate=a["mod"][k - 1][:, 5 * H:6 * H], branch=a["pm"][k - 1], dbranch=dbrm[q ^ 1],
-                                    dgate=a["dmod"][q ^ 1][:, 5 * H:6 * H])
+                                    dgate=a["dmod"][q ^ 1][:, 5 * H:6 * H], split=sp)
             else:
                 ops.ln_modulate_bwd(a["dxn"], a["h"][k], a["mean1"][k], a["rstd1"][k], mod[:, H:2 * H], a["dh"],
-                                    dmod[:, 0:H], dmod[:, H:2 * H], accumulate=True)
+                                    dmod[:, 0:H], dmod[:, H:2 * H], accumulate=True, split=sp)
             self._group([(p + "adaLN_modulation.1", dmod, a["s"]), (p + "mlp.fc1", dupre[q], a["xn2"][k]),
                          (p + "mlp.fc2", dbrm[q], a["u"][k]), (p + "attn.qkv", dqkv[q], a["xn1"][k]),
                          (p + "attn.proj", dbra[q], a["o"][k])],
@@ -443,9 +466,10 @@ class TrainCore:
         if after_bucket:
             after_bucket(D + 1)
 
-    def _dX(self, name, dY, out, epi=L.EPI_BIAS, side=False, gate=None):
+    def _dX(self, name, dY, out, epi=L.EPI_BIAS, side=False, gate=None, defer=None):
         """out (+)= dY W  with W [out, in] read K-major (K = out features)."""
-        return self._gemm(dY, self.pw.w[name + ".weight"], None, out=out, epi=epi, w_kmajor=True, side=side, gate=gate)
+        return self._gemm(dY, self.pw.w[name + ".weight"], None, out=out, epi=epi, w_kmajor=True, side=side, gate=gate,
+                          defer=defer)
 
     def backward(self, a, after_bucket=None):
         """a['deps'] holds d loss / d eps as the packed operand [C, Gp]; fills self.flat_g (overwrite).

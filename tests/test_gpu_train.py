@@ -706,3 +706,70 @@ def test_fp16_sampling_tolerance_on_trained_weights():
             worst = max(worst, e)
     with pytest.raises(ValueError, match="fp16"):
         TrainEngine(m, lr=1e-4, diffusion_step=1000, mask=mask)
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16"])
+def test_deferred_split_consumers_equal_the_reduce_launch(dt):
+    """stdiff_gemm with `defer` leaves a split-K result as partial products; the three consumers (LayerNorm forward with
+    the producer's bias + gated residual, LayerNorm backward with and without the gate product, attention backward) must
+    reproduce the unfused sequence -- reduce launch, then the plain entry point -- bit for bit."""
+    from stdiff_amd import ops, _lib as L
+    tdt = torch.float32 if dt == "fp32" else torch.bfloat16
+    gen = torch.Generator().manual_seed(11)
+    C_, H, K, heads = 200, 256, 2048, 4
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).to(DEV)
+    A, W, bias = r(C_, K).to(tdt), r(H, K, sc=K ** -0.5).to(tdt), r(H)
+    mod = r(C_, 3 * H).to(tdt)
+    res = r(C_, H)
+    ws = torch.empty(8 << 20, device=DEV, dtype=torch.float32)
+    # ---- forward: x = res + gate * (A W^T + bias), LayerNorm-modulate of x
+    x0, v0 = torch.empty(C_, H, device=DEV), torch.empty(C_, H, device=DEV, dtype=tdt)
+    ops.gemm(A, W, bias, out=x0, epi=L.EPI_GATE_RES, gate=mod[:, 2 * H:], res=res, out2=v0, workspace=ws)
+    m0, s0 = torch.empty(C_, device=DEV), torch.empty(C_, device=DEV)
+    y0 = ops.ln_modulate(x0, mod[:, :H], mod[:, H:2 * H], mean=m0, rstd=s0)
+    sp = L.SplitResult()
+    x1, v1 = torch.zeros(C_, H, device=DEV), torch.zeros(C_, H, device=DEV, dtype=tdt)
+    ops.gemm(A, W, bias, out=x1, epi=L.EPI_GATE_RES, gate=mod[:, 2 * H:], res=res, out2=v1, workspace=ws, defer=sp)
+    assert sp.slices >= 3 and sp.ldws >= H
+    m1, s1 = torch.empty(C_, device=DEV), torch.empty(C_, device=DEV)
+    y1 = ops.ln_modulate(x1, mod[:, :H], mod[:, H:2 * H], mean=m1, rstd=s1, split=sp, bias=bias, gate=mod[:, 2 * H:],
+                         res=res, v_out=v1)
+    for a_, b_ in ((x0, x1), (v0, v1), (y0, y1), (m0, m1), (s0, s1)):
+        assert torch.equal(a_, b_)
+    # without a workspace nothing splits: slices == 0 and the GEMM is complete
+    sp2 = L.SplitResult()
+    x2 = ops.gemm(A, W, bias, out=torch.empty(C_, H, device=DEV), defer=sp2)
+    assert sp2.slices == 0 and relerr(x2, A.float() @ W.float().T + bias) < 1e-4
+    # ---- LayerNorm backward of dy = dY W (K-major W), with and without the gate product
+    dY, Wk = r(C_, K).to(tdt), r(K, H, sc=K ** -0.5).to(tdt)
+    scale, gate, branch = r(C_, H, sc=0.3).to(tdt), r(C_, H).to(tdt), r(C_, H).to(tdt)
+    for with_gate in (True, False):
+        outs = []
+        for fused in (False, True):
+            sp = L.SplitResult() if fused else None
+            dy = torch.zeros(C_, H, device=DEV, dtype=tdt)
+            ops.gemm(dY, Wk, None, out=dy, w_kmajor=True, workspace=ws, defer=sp)
+            dx = torch.ones(C_, H, device=DEV)
+            dsh, dsc = torch.zeros(C_, H, device=DEV, dtype=tdt), torch.zeros(C_, H, device=DEV, dtype=tdt)
+            db, dg = torch.zeros(C_, H, device=DEV, dtype=tdt), torch.zeros(C_, H, device=DEV, dtype=tdt)
+            kw = dict(gate=gate, branch=branch, dbranch=db, dgate=dg) if with_gate else {}
+            ops.ln_modulate_bwd(dy, x0, m0, s0, scale, dx, dsh, dsc, accumulate=True, split=sp, **kw)
+            assert not fused or sp.slices >= 3
+            outs.append((dx, dsh, dsc, db, dg))
+        for a_, b_ in zip(*outs):
+            assert torch.equal(a_, b_)
+    # ---- attention backward with dout = dY W
+    Hh = heads * 64
+    qkv, Wp = r(C_, 3 * Hh).to(tdt), r(K, Hh, sc=K ** -0.5).to(tdt)
+    cu = torch.tensor([0, 120, C_], dtype=torch.int32, device=DEV)
+    lse = torch.empty(C_, heads, device=DEV)
+    o = ops.attention_fwd(qkv, cu, 120, heads, lse=lse)
+    outs = []
+    for fused in (False, True):
+        sp = L.SplitResult() if fused else None
+        do = torch.zeros(C_, Hh, device=DEV, dtype=tdt)
+        ops.gemm(dY, Wp, None, out=do, w_kmajor=True, workspace=ws, defer=sp)
+        dq = ops.attention_bwd(qkv, o, do, lse, cu, 120, heads, split=sp)
+        assert not fused or sp.slices >= 3
+        outs.append((do, dq))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
