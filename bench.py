@@ -292,7 +292,9 @@ def train_throughput(dtype, dev, g=G, h=H, steps=20, warmup=5, dist=None, rank=0
     from stdiff_amd import synth as O
     from stdiff_amd.train_engine import TrainEngine
     model = build_model(dtype, dev, g, h)
-    eng = TrainEngine(model, lr=1e-4, diffusion_step=T, mask=O.kfold_mask(g, 0))
+    # lazy_update (single process): the clip + AdamW update of iteration i is issued by iteration i + 1, range by range
+    # under its forward -- what normal_train_stDiff does; every timed iteration still contains one full update
+    eng = TrainEngine(model, lr=1e-4, diffusion_step=T, mask=O.kfold_mask(g, 0), lazy_update=True)
     assert eng.world == world
     st = torch.from_numpy(O.synth_expression(8 * BATCH, g, 1 + rank) * 2 - 1).to(dev)
     graph = world == 1 and dist is None    # one hipGraph per iteration (parallel dW branches); DDP steps are eager
@@ -307,6 +309,7 @@ def train_throughput(dtype, dev, g=G, h=H, steps=20, warmup=5, dist=None, rank=0
         eng.step(st[lo:lo + BATCH], st[lo:lo + BATCH], use_graph=graph)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    eng.finish()
     if dist is not None:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define STDIFF_ABI_VERSION 11
+#define STDIFF_ABI_VERSION 12
 
 enum { STDIFF_F32 = 0, STDIFF_BF16 = 1 };
 
@@ -305,6 +305,12 @@ typedef struct {
     void* bf16_mirror;   /* optional bf16 [n]: receives the updated parameters (the next forward's packed operands) */
 } stdiff_adamw_args;
 int stdiff_clip_adamw(const stdiff_adamw_args* a, void* stream);
+/* The same update in two parts: the scalars once (step counter, norm, clip factor, bias corrections), then any number
+ * of element ranges [lo, lo + count) of the flat buffers (lo % 4 == 0), each with the arithmetic above.  A caller that
+ * issues one range per layer on its own stream lets the NEXT iteration's forward start on a layer as soon as that
+ * layer's parameters are updated (stdiff_train_acts.param_ready).  stdiff_clip_adamw = prepare + range(0, n). */
+int stdiff_adamw_prepare(const stdiff_adamw_args* a, void* stream);
+int stdiff_adamw_range(const stdiff_adamw_args* a, int64_t lo, int64_t count, void* stream);
 
 /* ---------------------------------------------------------------- per-gene accuracy statistics (test-stDiff.py:203-364)
  * One pass over imputed x and measured y ([N, G] fp32): partials[chunk][k][g], k = sum x, sum y, sum xy, sum xx,
@@ -443,6 +449,12 @@ typedef struct {
     /* != 0: never leave a GEMM result as split-K partial products for its consumer (stdiff_gemm_args.defer): every split
      * GEMM is followed by its reduce launch, as before ABI 11 (A/B timing; results are bit-identical either way) */
     int no_defer;
+    /* Optional host array of depth + 2 hipEvent_t (NULL: none): stdiff_dit_train_forward makes its streams wait for
+     * param_ready[0] before the first use of the embedding layers' parameters (time MLP, cond, in), for
+     * param_ready[1 + k] before block k's, and for param_ready[depth + 1] before the final layer's -- the events an
+     * optimizer records after updating those ranges on another stream (stdiff_adamw_range), so that the update of
+     * iteration i - 1 runs under the forward of iteration i.  Already-recorded events only. */
+    void* const* param_ready;
 } stdiff_train_acts;
 /* side_stream (NULL = none): the adaLN projections of the forward and the weight-gradient jobs of the backward are
  * issued there and joined with events the library creates once per device (hipEventDisableTiming; no device memory):

@@ -10,7 +10,8 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 graph = (sys.argv[4] if len(sys.argv) > 4 else "1") == "1"
 dev = torch.device("cuda:0")
 st = torch.from_numpy(O.synth_expression(8 * 512, g, 1) * 2 - 1).to(dev)
-eng = TrainEngine(B.build_model("bf16", dev, g, h), lr=1e-4, diffusion_step=1000, mask=O.kfold_mask(g, 0))
+lazy = os.environ.get("LAZY", "1") == "1"
+eng = TrainEngine(B.build_model("bf16", dev, g, h), lr=1e-4, diffusion_step=1000, mask=O.kfold_mask(g, 0), lazy_update=lazy)
 for i in range(8):
     eng.step(st[:512], st[:512], use_graph=graph)
 torch.cuda.synchronize()
@@ -19,4 +20,5 @@ for i in range(n):
     lo = (i % 8) * 512
     eng.step(st[lo:lo + 512], st[lo:lo + 512], use_graph=graph)
 torch.cuda.synchronize()
-print(f"{(time.perf_counter() - t0) / n * 1e3:.3f} ms/step, graph={graph}")
+print(f"{(time.perf_counter() - t0) / n * 1e3:.3f} ms/step, graph={graph}, lazy={lazy}")
+eng.finish()

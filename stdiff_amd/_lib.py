@@ -92,7 +92,7 @@ class TrainActs(C.Structure):
                                   "da1", "dhT")] + \
                [("tr", (vp * 2) * 2), ("splitk_ws", vp), ("splitk_bytes", C.c_longlong),
                 ("splitk_ws_side", vp), ("splitk_side_bytes", C.c_longlong), ("dbr_b", vp * 3), ("dqkv_b", vp),
-                ("no_defer", i32)]
+                ("no_defer", i32), ("param_ready", C.POINTER(vp))]
 
 
 class DwProblem(C.Structure):
@@ -156,6 +156,8 @@ _SIGS = {
     "stdiff_colsum": (i32, [vp, i32, i32, vp, i32, i32, i32, vp]),
     "stdiff_grad_sumsq": (i32, [vp, i64, vp, vp]),
     "stdiff_clip_adamw": (i32, [C.POINTER(AdamWArgs), vp]),
+    "stdiff_adamw_prepare": (i32, [C.POINTER(AdamWArgs), vp]),
+    "stdiff_adamw_range": (i32, [C.POINTER(AdamWArgs), i64, i64, vp]),
     "stdiff_dit_forward": (i32, [C.POINTER(DitWeights), C.POINTER(DitWorkspace), vp, vp, vp, i32, vp]),
     "stdiff_dit_train_forward": (i32, [C.POINTER(TrainWeights), C.POINTER(TrainActs), vp, vp, vp]),
     "stdiff_dit_backward": (i32, [C.POINTER(TrainWeights), C.POINTER(TrainActs), vp, BucketFn, vp, vp]),
@@ -187,7 +189,7 @@ def lib(fp16=False):
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.stdiff_abi_version() != 11:
+        if L.stdiff_abi_version() != 12:
             raise RuntimeError(f"{base} ABI version mismatch")
         if L.stdiff_h16_format() != int(bool(fp16)):
             raise RuntimeError(f"{base} was built with the wrong 16-bit operand format")

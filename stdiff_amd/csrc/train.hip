@@ -475,10 +475,49 @@ extern "C" int stdiff_grad_sumsq(const float* grads, int64_t n, float* sumsq, vo
     return STDIFF_OK;
 }
 
-extern "C" int stdiff_clip_adamw(const stdiff_adamw_args* a, void* stream) {
+namespace {
+int adamw_check(const stdiff_adamw_args* a) {
     STDIFF_CHECK_ARG(a && a->params && a->grads && a->exp_avg && a->exp_avg_sq && a->sumsq && a->step_dev && a->scal &&
                      a->n >= 0);
     STDIFF_CHECK_ARG(al16(a->params) && al16(a->grads) && al16(a->exp_avg) && al16(a->exp_avg_sq) && al8(a->bf16_mirror));
+    return STDIFF_OK;
+}
+}  // namespace
+
+// The two halves of stdiff_clip_adamw for callers that update the flat buffer range by range (one range per layer, so
+// that the next forward can start on a layer as soon as ITS parameters are updated): the scalars once, then any number
+// of ranges, each the same arithmetic on elements [lo, lo + count).
+extern "C" int stdiff_adamw_prepare(const stdiff_adamw_args* a, void* stream) {
+    int rc = adamw_check(a);
+    if (rc != STDIFF_OK) return rc;
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->sumsq, a->step_dev, a->scal,
+                       a->max_norm, a->grad_scale, a->lr, a->beta1, a->beta2);
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}
+
+extern "C" int stdiff_adamw_range(const stdiff_adamw_args* a, int64_t lo, int64_t count, void* stream) {
+    int rc = adamw_check(a);
+    if (rc != STDIFF_OK) return rc;
+    STDIFF_CHECK_ARG(lo >= 0 && count >= 0 && lo + count <= a->n);
+    if (lo % 4) return STDIFF_ERR_ALIGN;
+    if (count == 0) return STDIFF_OK;
+    // ONE block per CU: a range runs beside the next forward's batch-sized GEMMs, which are latency-bound -- with two
+    // blocks per CU (the stand-alone optimum) the streaming update saturates the memory system and those GEMMs run 2-4x
+    // slower.  Measured on the overlapped iteration (STDIFF_ADAMW_RANGE_BLOCKS sweep, H = 1024 / configs[2] shape):
+    // 192: 2.47 / 6.69 ms, 256: 2.44 / 6.31, 320: 2.64 / 6.86, 512: 2.60 / 6.64.
+    static const int xblocks = [] { const char* e = getenv("STDIFF_ADAMW_RANGE_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : cu_count(); }();
+    dim3 grid((unsigned)std::min<size_t>(((size_t)count / 4 + 256) / 256, (size_t)xblocks));
+    hipLaunchKernelGGL(clip_adamw_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a->params + lo, a->grads + lo,
+                       a->exp_avg + lo, a->exp_avg_sq + lo, count, a->scal, a->lr, a->beta1, a->beta2, a->eps,
+                       a->weight_decay, a->bf16_mirror ? (bf16_t*)a->bf16_mirror + lo : nullptr);
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}
+
+extern "C" int stdiff_clip_adamw(const stdiff_adamw_args* a, void* stream) {
+    int rc0 = adamw_check(a);
+    if (rc0 != STDIFF_OK) return rc0;
     if (a->n == 0) return STDIFF_OK;
     hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->sumsq, a->step_dev, a->scal,
                        a->max_norm, a->grad_scale, a->lr, a->beta1, a->beta2);

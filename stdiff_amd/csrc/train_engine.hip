@@ -335,8 +335,14 @@ extern "C" int stdiff_dit_train_forward(const stdiff_train_weights* w, const std
         STDIFF_CHECK_ARG(a->splitk_ws_side || !a->splitk_ws);
         TRY(events_for_device(&c.ev));
     }
+    // parameters updated range by range on another stream (stdiff_adamw_range): wait where a range is first used
+    auto ready = [&](hipStream_t st, int range) -> int {
+        if (a->param_ready && a->param_ready[range]) TRYH(hipStreamWaitEvent(st, (hipEvent_t)a->param_ready[range], 0));
+        return STDIFF_OK;
+    };
     // t -> sinusoidal embedding -> time MLP (stDiff_model.py:52-80), c = time_emb(t) + cond_layer(y) (:237), s = silu(c)
     TRY(stdiff_timestep_embedding(t, w->freqs, a->e0, 256, dt, C, stream));
+    TRY(ready(c.main, 0));
     TRY(c.lin(false, C, H, 256, a->e0, 256, w->t0, 256, a->e1, H, dt, STDIFF_EPI_SILU, nullptr, 0, nullptr, 0, a->a1, H));
     TRY(c.lin(false, C, H, H, a->e1, H, w->t2, H, a->temb, H, STDIFF_F32));
     TRY(c.lin(false, C, H, Gp, a->yp, Gp, w->cond, Gp, a->c, H, STDIFF_F32, STDIFF_EPI_ADD, nullptr, 0, a->temb, H));
@@ -347,6 +353,7 @@ extern "C" int stdiff_dit_train_forward(const stdiff_train_weights* w, const std
         TRYH(hipEventRecord(c.ev[0], c.main));
         TRYH(hipStreamWaitEvent(c.side, c.ev[0], 0));
         for (int k = 0; k <= D; ++k) {
+            TRY(ready(c.side, 1 + k));
             if (k < D) TRY(c.lin(true, C, 6 * H, H, a->s, H, w->blocks[k].ada, H, a->blocks[k].mod, 6 * H, dt));
             else TRY(c.lin(true, C, 2 * H, H, a->s, H, w->fada, H, a->fmod, 2 * H, dt));
             TRYH(hipEventRecord(c.ev[3 + k], c.side));
@@ -366,6 +373,7 @@ extern "C" int stdiff_dit_train_forward(const stdiff_train_weights* w, const std
         float* h_next = k + 1 < D ? a->blocks[k + 1].h : a->h_last;
         STDIFF_CHECK_ARG(s.h && s.hmid && s.mod && s.xn1 && s.xn2 && s.qkv && s.o && s.lse && s.pa && s.pm && s.upre &&
                          s.u && s.mean1 && s.rstd1 && s.mean2 && s.rstd2);
+        TRY(ready(c.main, 1 + k));
         if (fork) TRYH(hipStreamWaitEvent(c.main, c.ev[3 + k], 0));
         else TRY(c.lin(false, C, 6 * H, H, a->s, H, b.ada, H, s.mod, 6 * H, dt));
         TRY(c.ln(pend, s.h, H, col(s.mod, dt, 0), col(s.mod, dt, H), 6 * H, s.xn1, s.mean1, s.rstd1));
@@ -385,6 +393,7 @@ extern "C" int stdiff_dit_train_forward(const stdiff_train_weights* w, const std
         TRY(c.lin(false, C, H, 4 * H, s.u, 4 * H, b.fc2, 4 * H, h_next, H, STDIFF_F32, STDIFF_EPI_GATE_RES,
                   col(s.mod, dt, 5 * H), 6 * H, s.hmid, H, s.pm, H, fork ? &pend.sp : nullptr));
     }
+    TRY(ready(c.main, 1 + D));
     if (fork) TRYH(hipStreamWaitEvent(c.main, c.ev[3 + D], 0));
     else TRY(c.lin(false, C, 2 * H, H, a->s, H, w->fada, H, a->fmod, 2 * H, dt));
     TRY(c.ln(pend, a->h_last, H, col(a->fmod, dt, 0), col(a->fmod, dt, H), 2 * H, a->xnf, a->meanf, a->rstdf));

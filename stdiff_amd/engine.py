@@ -487,7 +487,7 @@ def lane_streams(device, n):
 
 def aux_stream(device, name):
     """A cached non-default stream of `device` for role `name` ('side': the weight-gradient branch of a captured
-    training iteration)."""
+    training iteration; 'opt': the optimizer update that runs under the next forward)."""
     key = (_dev_index(device), name)
     st = _STREAMS.get(key)
     if st is None:

@@ -25,7 +25,8 @@ def normal_train_stDiff(model,
     gradients are averaged over ranks before the clip."""
     model.to(device)
     model.train()
-    eng = TrainEngine(model, lr=lr, diffusion_step=diffusion_step, mask=mask)
+    # lazy_update: the clip + AdamW update of iteration i runs under the forward of iteration i + 1 (same results)
+    eng = TrainEngine(model, lr=lr, diffusion_step=diffusion_step, mask=mask, lazy_update=True)
     # Each iteration is replayed as one hipGraph per batch size (STDIFF_TRAIN_GRAPH=0: eager enqueue).  The graph has
     # the weight-gradient GEMMs on parallel branches (train_engine.py), which the eager enqueue cannot afford:
     # 3.42 against 3.55 ms per 512-cell step at H=1024.  With a process group the step is always eager (the bucketed
@@ -42,6 +43,8 @@ def normal_train_stDiff(model,
             loss, _ = eng.step(x, x_cond, use_graph=use_graph)
             epoch_loss += loss
             n = i + 1
+        if epoch + 1 == num_epoch:
+            eng.finish()                        # the last iteration's update
         epoch_loss = float(epoch_loss) / max(n, 1)
         if is_tqdm:
             t_epoch.set_postfix_str(f'{pred_type} loss:{epoch_loss:.5f}')

@@ -315,6 +315,29 @@ def grad_sumsq(g, sumsq):
     check(lib().stdiff_grad_sumsq(ptr(g), g.numel(), ptr(sumsq), stream()))
 
 
+def adamw_args(p, g, m, v, sumsq, step_dev, scal, lr, max_norm=1.0, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8,
+               weight_decay=0.0, bf16_mirror=None):
+    """stdiff_adamw_args over the flat buffers (for adamw_prepare / adamw_range: the update issued range by range)."""
+    require_gpu(p, g, m, v, sumsq, step_dev, scal, bf16_mirror)
+    a = L.AdamWArgs()
+    a.params, a.grads, a.exp_avg, a.exp_avg_sq, a.n = ptr(p), ptr(g), ptr(m), ptr(v), p.numel()
+    a.sumsq, a.step_dev, a.scal = ptr(sumsq), ptr(step_dev), ptr(scal)
+    a.max_norm, a.grad_scale, a.lr = max_norm, grad_scale, lr
+    a.beta1, a.beta2, a.eps, a.weight_decay = betas[0], betas[1], eps, weight_decay
+    if bf16_mirror is not None:
+        assert bf16_mirror.dtype == torch.bfloat16 and bf16_mirror.numel() == p.numel()
+        a.bf16_mirror = ptr(bf16_mirror)
+    return a
+
+
+def adamw_prepare(a):
+    check(lib().stdiff_adamw_prepare(C.byref(a), stream()))
+
+
+def adamw_range(a, lo, count):
+    check(lib().stdiff_adamw_range(C.byref(a), lo, count, stream()))
+
+
 def clip_adamw(p, g, m, v, sumsq, step_dev, scal, lr, max_norm=1.0, grad_scale=1.0, betas=(0.9, 0.999), eps=1e-8,
                weight_decay=0.0, bf16_mirror=None):
     require_gpu(p, g, m, v, sumsq, step_dev, scal, bf16_mirror)

@@ -245,15 +245,29 @@ class TrainCore:
         return self._side.cuda_stream if on else None
 
     # ------------------------------------------------------------------ forward (stDiff_model.py:231-243)
-    def forward(self, a, t):
-        """a['xp'], a['yp'] hold the packed inputs; returns eps fp32 [C, G] (a['eps'])."""
+    def forward(self, a, t, param_ready=None):
+        """a['xp'], a['yp'] hold the packed inputs; returns eps fp32 [C, G] (a['eps']).
+        param_ready: depth + 2 recorded torch.cuda.Event (embedding layers, block 0 .., final layer): the forward waits
+        for each where that range of parameters is first used (an optimizer updating them on another stream)."""
         if self.c_enqueue:
             side = self._c_side()
-            L.check(L.lib().stdiff_dit_train_forward(self._c_weights(), self._c_acts(a), L.ptr(t), side, L.stream()))
+            ca = self._c_acts(a)
+            if param_ready is not None:
+                arr = (L.vp * len(param_ready))(*[e.cuda_event for e in param_ready])
+                ca.param_ready = L.C.cast(arr, L.C.POINTER(L.vp))
+            try:
+                L.check(L.lib().stdiff_dit_train_forward(self._c_weights(), ca, L.ptr(t), side, L.stream()))
+            finally:
+                ca.param_ready = L.C.cast(None, L.C.POINTER(L.vp))
             return a["eps"]
         H, D = self.H, self.depth
         g = self._gemm
+
+        def params_ready(i, st=None):
+            if param_ready is not None:
+                (st or torch.cuda.current_stream()).wait_event(param_ready[i])
         ops.timestep_embedding(t, self.pw.freqs, out=a["e0"])
+        params_ready(0)
         w, b = self._lin("time_emb.mlp.0")
         g(a["e0"], w, b, out=a["e1"], epi=L.EPI_SILU, out2=a["a1"])
         w, b = self._lin("time_emb.mlp.2")
@@ -274,6 +288,7 @@ class TrainCore:
             with torch.cuda.stream(self._side):
                 for k in range(D + 1):
                     name = f"blks.{k}.adaLN_modulation.1" if k < D else "out_layer.adaLN_modulation.1"
+                    params_ready(1 + k, self._side)
                     w, b = self._lin(name)
                     g(a["s"], w, b, out=a["mod"][k] if k < D else a["fmod"], side=True)
                     ev = torch.cuda.Event()
@@ -290,6 +305,7 @@ class TrainCore:
         for k in range(D):
             p = f"blks.{k}."
             mod = a["mod"][k]
+            params_ready(1 + k)
             if mod_ready is None:
                 w, b = self._lin(p + "adaLN_modulation.1")
                 g(a["s"], w, b, out=mod)
@@ -312,6 +328,7 @@ class TrainCore:
             pend = dict(split=sr(mod_ready is not None), bias=b, gate=mod[:, 5 * H:6 * H], res=a["hmid"][k], v_out=a["pm"][k])
             g(a["u"][k], w, b, out=a["h"][k + 1], epi=L.EPI_GATE_RES, gate=mod[:, 5 * H:6 * H], res=a["hmid"][k], out2=a["pm"][k],
               defer=pend["split"])
+        params_ready(1 + D)
         if mod_ready is None:
             w, b = self._lin("out_layer.adaLN_modulation.1")
             g(a["s"], w, b, out=a["fmod"])
@@ -554,7 +571,12 @@ class TrainEngine(TrainCore):
     """One reference training iteration per step() (stDiff_train.py:59-81)."""
 
     def __init__(self, model, lr=1e-4, diffusion_step=1000, mask=None, weight_decay=0.0, betas=(0.9, 0.999),
-                 eps=1e-8, max_norm=1.0, process_group=None):
+                 eps=1e-8, max_norm=1.0, process_group=None, lazy_update=False):
+        """lazy_update=True (single process): step() leaves its clip + AdamW update PENDING and the next step() issues
+        it on a stream of its own, one range of the flat buffers per layer, while its forward is already running --
+        the forward waits per layer for that layer's range (stdiff_adamw_range, stdiff_train_acts.param_ready).  Same
+        arithmetic in the same order, so parameters, losses and gradients equal the eager sequence bit for bit; the
+        parameters (and scal[3], the gradient norm) are current only after the next step() or finish()."""
         super().__init__(model)
         from .model.stDiff_scheduler import NoiseScheduler
         dev = self.device
@@ -598,6 +620,14 @@ class TrainEngine(TrainCore):
                 self.pw.refresh()
         self.buckets = self.bucket_ranges()
         self._graphs, self._stream = {}, None
+        self.lazy = bool(lazy_update) and self.world == 1 and os.environ.get("STDIFF_TRAIN_LAZY", "1") != "0"
+        self._pending, self._opt_stream = False, None
+        # update ranges in the order the forward first touches them: embedding layers, block 0 .. depth-1, final layer
+        # (the all-reduce buckets in reverse)
+        self.update_ranges = [self.buckets[-1]] + self.buckets[-2:0:-1] + [self.buckets[0]]
+        lo0, hi0 = self.update_ranges[0]
+        assert all(lo0 <= self.offs[n] < hi0 for n in self.pw.w if n not in self.mirrored), \
+            "operands that need a repack after the optimizer must lie in the first update range"
 
     def step(self, x, x_cond, noise=None, timesteps=None, use_graph=False):
         """x, x_cond: fp32 [C, G] on the device.  Returns (loss[1], grad_norm[1]) device tensors (no host sync).
@@ -608,7 +638,8 @@ class TrainEngine(TrainCore):
         C = x.shape[0]
         dev = self.device
         self.pw.fused_stale = True       # the optimizer kernel rewrites the operand mirror without going through refresh()
-        if use_graph and self.world == 1:
+        if use_graph and self.world == 1 and not (self.lazy and not self._pending):
+            # (a lazy engine's first step has no pending update: enqueued eagerly, the graph is captured on the second)
             return self._step_graph(x, x_cond, noise, timesteps)
         a = self.acts(C)
         if noise is None:
@@ -618,10 +649,54 @@ class TrainEngine(TrainCore):
         self._enqueue(a, x, x_cond, noise, timesteps)
         return self.loss, self.scal[3:4]
 
+    def _adamw_args(self):
+        return ops.adamw_args(self.flat_p, self.flat_g, self.m, self.v, self.sumsq, self.step_dev, self.scal, self.lr,
+                              max_norm=self.max_norm, grad_scale=1.0 / self.world, betas=self.betas, eps=self.eps,
+                              weight_decay=self.wd, bf16_mirror=self.mirror)
+
+    def _enqueue_pending_update(self):
+        """The update the previous step() left pending, on the optimizer stream, one range per layer; returns the events
+        recorded after each range (the forward's param_ready)."""
+        if self._opt_stream is None:
+            from .engine import aux_stream
+            # (default priority: a high-priority optimizer stream made the iteration 40 % slower, and high-priority
+            # chain streams hung a captured iteration on this stack -- neither is used)
+            self._opt_stream = aux_stream(self.device, "opt")
+        cur = torch.cuda.current_stream()
+        start = torch.cuda.Event()
+        start.record(cur)
+        self._opt_stream.wait_event(start)
+        events = [start]                             # kept alive with the others (a graph may be recording them)
+        with torch.cuda.stream(self._opt_stream):
+            args = self._adamw_args()
+            ops.adamw_prepare(args)
+            for i, (lo, hi) in enumerate(self.update_ranges):
+                ops.adamw_range(args, lo, hi - lo)
+                if i == 0:
+                    self.refresh_weights()             # gene-padded in / cond operands: all inside the first range
+                ev = torch.cuda.Event()
+                ev.record(self._opt_stream)
+                events.append(ev)
+        self._fork_event = events.pop(0)
+        return events
+
+    def finish(self):
+        """Applies the update a lazy step() left pending (no-op otherwise): call before reading parameters."""
+        if self._pending:
+            ops.clip_adamw(self.flat_p, self.flat_g, self.m, self.v, self.sumsq, self.step_dev, self.scal, self.lr,
+                           max_norm=self.max_norm, grad_scale=1.0 / self.world, betas=self.betas, eps=self.eps,
+                           weight_decay=self.wd, bf16_mirror=self.mirror)
+            self.refresh_weights()
+            self._pending = False
+
     def _enqueue(self, a, x, x_cond, noise, timesteps):
+        ready = self._enqueue_pending_update() if (self.lazy and self._pending) else None
         ops.add_noise_splice(x, noise, timesteps, self.sa, self.sb, self.mask, xp=a["xp"])   # :65-70
         ops.pack_rows(x_cond, self.Gp, self.tdt, out=a["yp"])
-        eps = self.forward(a, timesteps)                                               # :72
+        eps = self.forward(a, timesteps, param_ready=ready)                            # :72
+        if ready is not None:
+            a["_ready_events"] = (self._fork_event, ready)      # a captured graph keeps its events alive
+            torch.cuda.current_stream().wait_event(ready[-1])      # the update has read every gradient
         self.loss.zero_()
         ops.masked_mse(eps, noise, self.mask, self.loss, dp=a["deps"])                 # :75 (+ d loss / d eps)
         handles = []
@@ -638,6 +713,9 @@ class TrainEngine(TrainCore):
             h.wait()
         self.sumsq.zero_()
         ops.grad_sumsq(self.flat_g, self.sumsq)
+        if self.lazy:
+            self._pending = True                 # clip + AdamW ride under the next step's forward (or finish())
+            return
         ops.clip_adamw(self.flat_p, self.flat_g, self.m, self.v, self.sumsq, self.step_dev, self.scal, self.lr,
                        max_norm=self.max_norm, grad_scale=1.0 / self.world, betas=self.betas, eps=self.eps,
                        weight_decay=self.wd, bf16_mirror=self.mirror)                  # :78-80

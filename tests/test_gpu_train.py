@@ -773,3 +773,48 @@ def test_deferred_split_consumers_equal_the_reduce_launch(dt):
         assert not fused or sp.slices >= 3
         outs.append((do, dq))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("dtype,use_graph,enqueue", [("fp32", False, "c"), ("bf16", True, "c"), ("bf16", False, "py"),
+                                                      ("fp32", True, "c")])
+def test_lazy_update_equals_eager_update(dtype, use_graph, enqueue, monkeypatch):
+    """TrainEngine(lazy_update=True): the clip + AdamW update of iteration i is issued by iteration i + 1 on a stream of
+    its own, one range of the flat buffers per layer, with the forward waiting per layer (stdiff_adamw_range,
+    param_ready).  Same arithmetic: after finish() parameters, moments and every loss equal the eager engine's; before
+    finish() the parameters are those of the previous update."""
+    from stdiff_amd.train_engine import TrainEngine
+    monkeypatch.setenv("STDIFF_TRAIN_ENQUEUE", enqueue)
+    G, H, depth, heads, T, C = 72, 128, 3, 4, 1000, 96
+    mask = O.kfold_mask(G, 1)
+    st = (O.synth_expression(C, G, 9) * 2 - 1).astype(np.float32)
+    x = torch.from_numpy(st).to(DEV)
+    xc = (x * torch.from_numpy(mask).to(DEV)).float()
+    res = {}
+    for lazy in (False, True):
+        m, _ = build(G, H, depth, heads, 71, dtype)
+        te = TrainEngine(m, lr=1e-3, diffusion_step=T, mask=mask, lazy_update=lazy)
+        assert te.lazy == lazy
+        gen = torch.Generator().manual_seed(5)
+        losses = []
+        for i in range(5):
+            noise = torch.randn(C, G, generator=gen).to(DEV)
+            tt = torch.randint(1, T, (C,), generator=gen).to(DEV)
+            loss, _ = te.step(x, xc, noise=noise, timesteps=tt, use_graph=use_graph)
+            losses.append(float(loss))
+            if lazy and i == 3:
+                before = te.flat_p.clone()
+        if lazy:
+            assert te._pending
+            stale = te.flat_p.clone()
+            te.finish()
+            assert not te._pending and not torch.equal(stale, te.flat_p)
+            te.finish()                                   # idempotent
+        res[lazy] = (losses, te.flat_p.clone(), te.m.clone(), te.v.clone(), int(te.step_dev))
+    assert res[True][4] == res[False][4] == 5
+    # losses: summed with float atomics (last bits vary run to run); tensors: exact unless a step clipped (the clip
+    # factor carries the norm's varying last bits)
+    for a_, b_ in zip(res[True][0], res[False][0]):
+        assert abs(a_ - b_) < 1e-5 * abs(b_)
+    tol = 1e-4 if dtype == "fp32" else 2e-2
+    for k in (1, 2, 3):
+        assert relerr(res[True][k], res[False][k]) < tol, k
