@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define STDIFF_ABI_VERSION 12
+#define STDIFF_ABI_VERSION 13
 
 enum { STDIFF_F32 = 0, STDIFF_BF16 = 1 };
 
@@ -415,6 +415,7 @@ typedef struct {
     const stdiff_train_block* blocks;           /* host array [depth] */
     const float* freqs;                         /* as for stdiff_timestep_embedding */
 } stdiff_train_weights;
+struct stdiff_grad_ranges { float* sumsq; const float* lo[64]; long long count[64]; };
 typedef struct {            /* saved by block k's forward */
     float* h; float* hmid;                      /* fp32 [C,H]: block input, after the attention branch */
     void* mod;                                  /* [C,6H] adaLN output */
@@ -455,6 +456,12 @@ typedef struct {
      * optimizer records after updating those ranges on another stream (stdiff_adamw_range), so that the update of
      * iteration i - 1 runs under the forward of iteration i.  Already-recorded events only. */
     void* const* param_ready;
+    /* Optional (NULL: none; honoured by the grouped backward only): the squared gradient norm accumulated range by range
+     * as the backward finishes each gradient bucket -- *sumsq += sum g^2 over [lo[i], lo[i] + count[i]) for bucket i of
+     * stdiff_bucket_fn's numbering (depth + 2 buckets), issued on the stream that ran the bucket's last launches, so the
+     * norm pass of clip_grad_norm_ (stDiff_train.py:78) hides under the input-gradient chain.  The caller zeroes *sumsq
+     * before the backward and must not use this under data parallelism (the norm is that of the REDUCED gradient). */
+    const struct stdiff_grad_ranges* grad_ranges;
 } stdiff_train_acts;
 /* side_stream (NULL = none): the adaLN projections of the forward and the weight-gradient jobs of the backward are
  * issued there and joined with events the library creates once per device (hipEventDisableTiming; no device memory):

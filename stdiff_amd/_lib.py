@@ -82,6 +82,11 @@ class TrainBlockActs(C.Structure):
                                   "mean1", "rstd1", "mean2", "rstd2")]
 
 
+class GradRanges(C.Structure):
+    """struct stdiff_grad_ranges: the gradient-norm pass folded into the backward, one range per gradient bucket."""
+    _fields_ = [("sumsq", vp), ("lo", vp * 64), ("count", C.c_longlong * 64)]
+
+
 class TrainActs(C.Structure):
     _fields_ = [("C", i32), ("cu_rows", vp)] + \
                [(n, vp) for n in ("xp", "yp", "e0", "a1", "e1", "temb", "c", "s")] + \
@@ -92,7 +97,8 @@ class TrainActs(C.Structure):
                                   "da1", "dhT")] + \
                [("tr", (vp * 2) * 2), ("splitk_ws", vp), ("splitk_bytes", C.c_longlong),
                 ("splitk_ws_side", vp), ("splitk_side_bytes", C.c_longlong), ("dbr_b", vp * 3), ("dqkv_b", vp),
-                ("no_defer", i32), ("param_ready", C.POINTER(vp))]
+                ("no_defer", i32), ("param_ready", C.POINTER(vp)),
+                ("grad_ranges", C.POINTER(GradRanges))]
 
 
 class DwProblem(C.Structure):
@@ -189,7 +195,7 @@ def lib(fp16=False):
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.stdiff_abi_version() != 12:
+        if L.stdiff_abi_version() != 13:
             raise RuntimeError(f"{base} ABI version mismatch")
         if L.stdiff_h16_format() != int(bool(fp16)):
             raise RuntimeError(f"{base} was built with the wrong 16-bit operand format")

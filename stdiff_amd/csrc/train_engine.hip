@@ -159,6 +159,12 @@ struct Ctx {
         done_i ^= 1;
         return STDIFF_OK;
     }
+    // gradient-norm contribution of bucket i (stdiff_train_acts.grad_ranges), on the stream that finished the bucket
+    int norm(bool on_side, int bucket) const {
+        const stdiff_grad_ranges* r = a->grad_ranges;
+        if (!r || !r->sumsq || bucket < 0 || bucket >= 64 || !r->lo[bucket] || r->count[bucket] <= 0) return STDIFF_OK;
+        return stdiff_grad_sumsq(r->lo[bucket], r->count[bucket], r->sumsq, st(on_side));
+    }
     static stdiff_dw_problem prob(const stdiff_train_linear& l, int m, int n, const void* dY, int lddy, const void* X,
                                   int ldx) {
         stdiff_dw_problem q = {};
@@ -248,6 +254,7 @@ int backward_grouped(Ctx& c, stdiff_bucket_fn after_bucket, void* user) {
         if (!odd_genes) g.p[g.n++] = Ctx::prob(w->out, G, H, a->deps, Gp, a->xnf, H);
         // d loss / d s accumulates over all adaLN projections on the stream that runs the groups, in issue order
         TRY(c.group(g, [&](bool sd) {
+            TRY(c.norm(sd, 0));
             return c.dX(sd, C, a->dfmod, 2 * H, 2 * H, w->fada, 2 * H, H, a->ds32, H, STDIFF_F32);
         }));
     }
@@ -289,6 +296,7 @@ int backward_grouped(Ctx& c, stdiff_bucket_fn after_bucket, void* user) {
         g.p[g.n++] = Ctx::prob(b.qkv, 3 * H, H, dqkv[q], 3 * H, s.xn1, H);
         g.p[g.n++] = Ctx::prob(b.proj, H, H, dbra[q], H, s.o, H);
         TRY(c.group(g, [&](bool sd) {
+            TRY(c.norm(sd, D - k));
             return c.dX(sd, C, dmod, 6 * H, 6 * H, b.ada, 6 * H, H, a->ds32, H, STDIFF_F32, STDIFF_EPI_ACCUM);
         }));
     }
@@ -314,6 +322,7 @@ int backward_grouped(Ctx& c, stdiff_bucket_fn after_bucket, void* user) {
             TRY(c.dW_enqueue(false, w->in, H, G, a->dhT, H, H, a->xp, Gp, Gp));
             TRY(c.dW_enqueue(false, w->cond, H, G, a->dcT, H, H, a->yp, Gp, Gp));
         }
+        TRY(c.norm(false, D + 1));
     }
     if (after_bucket) after_bucket(D + 1, user);
     return STDIFF_OK;

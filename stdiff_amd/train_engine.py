@@ -431,7 +431,15 @@ class TrainCore:
         first = [("out_layer.adaLN_modulation.1", a["dfmod"], a["s"])]
         if not odd:
             first.append(("out_layer.linear", deps, a["xnf"], G))
-        self._group(first, then=lambda sd: self._dX("out_layer.adaLN_modulation.1", a["dfmod"], a["ds32"], side=sd))
+        def norm(i):
+            if self._norm is not None:
+                lo, hi = self._norm[1][i]
+                ops.grad_sumsq(self.flat_g[lo:hi], self._norm[0])
+
+        def then_first(sd):
+            norm(0)
+            self._dX("out_layer.adaLN_modulation.1", a["dfmod"], a["ds32"], side=sd)
+        self._group(first, then=then_first)
         for k in range(D - 1, -1, -1):
             p, q = f"blks.{k}.", k & 1
             mod, dmod = a["mod"][k], a["dmod"][q]
@@ -462,8 +470,9 @@ class TrainCore:
             self._group([(p + "adaLN_modulation.1", dmod, a["s"]), (p + "mlp.fc1", dupre[q], a["xn2"][k]),
                          (p + "mlp.fc2", dbrm[q], a["u"][k]), (p + "attn.qkv", dqkv[q], a["xn1"][k]),
                          (p + "attn.proj", dbra[q], a["o"][k])],
-                        then=lambda sd, p=p, dmod=dmod: self._dX(p + "adaLN_modulation.1", dmod, a["ds32"],
-                                                                 epi=L.EPI_ACCUM, side=sd))
+                        then=lambda sd, p=p, dmod=dmod, k=k: (norm(D - k),
+                                                              self._dX(p + "adaLN_modulation.1", dmod, a["ds32"],
+                                                                       epi=L.EPI_ACCUM, side=sd)))
         self._side_join()
         if after_bucket:
             after_bucket(D)
@@ -480,6 +489,7 @@ class TrainCore:
         if odd:
             self._dW_enqueue(a, "in_layer.0", a["dhT_"], a["xp"], None, False)
             self._dW_enqueue(a, "cond_layer.0", a["dcT_"], a["yp"], None, False)
+        norm(D + 1)
         if after_bucket:
             after_bucket(D + 1)
 
@@ -488,12 +498,28 @@ class TrainCore:
         return self._gemm(dY, self.pw.w[name + ".weight"], None, out=out, epi=epi, w_kmajor=True, side=side, gate=gate,
                           defer=defer)
 
-    def backward(self, a, after_bucket=None):
+    def backward(self, a, after_bucket=None, sumsq=None):
         """a['deps'] holds d loss / d eps as the packed operand [C, Gp]; fills self.flat_g (overwrite).
-        after_bucket(i) is called when the i-th range of bucket_ranges() is final (DDP overlap)."""
+        after_bucket(i) is called when the i-th range of bucket_ranges() is final (DDP overlap).
+        sumsq (fp32 [1], zeroed by the caller; grouped backward only): the squared gradient norm is accumulated bucket
+        by bucket as the backward finishes them, beside the input-gradient chain, instead of in a pass of its own."""
         H, D = self.H, self.depth
+        self._norm = None
+        if sumsq is not None:
+            assert "dbr_b" in a, "the folded gradient norm needs the grouped backward"
+            self._norm = (sumsq, self.bucket_ranges())
         if self.c_enqueue:
             side = self._c_side()
+            ca = self._c_acts(a)
+            if self._norm is not None:
+                gr = L.GradRanges()
+                gr.sumsq = L.ptr(sumsq)
+                for i, (lo, hi) in enumerate(self._norm[1]):
+                    gr.lo[i], gr.count[i] = L.ptr(self.flat_g) + 4 * lo, hi - lo
+                a["_grad_ranges"] = gr
+                ca.grad_ranges = L.C.pointer(gr)
+            else:
+                ca.grad_ranges = L.C.cast(None, L.C.POINTER(L.GradRanges))
             err = []
 
             def hook(i, _user):               # an exception must not unwind through the C frames
@@ -620,6 +646,7 @@ class TrainEngine(TrainCore):
                 self.pw.refresh()
         self.buckets = self.bucket_ranges()
         self._graphs, self._stream = {}, None
+        self.fold_norm = os.environ.get("STDIFF_TRAIN_FOLD_NORM", "1") != "0"
         self.lazy = bool(lazy_update) and self.world == 1 and os.environ.get("STDIFF_TRAIN_LAZY", "1") != "0"
         self._pending, self._opt_stream = False, None
         # update ranges in the order the forward first touches them: embedding layers, block 0 .. depth-1, final layer
@@ -708,11 +735,17 @@ class TrainEngine(TrainCore):
             else:
                 torch.cuda.synchronize(self.device)      # gloo + CUDA tensors behind a busy stream stalled on this stack
                 self.dist.all_reduce(self.flat_g[lo:hi], group=self.pg)
-        self.backward(a, after_bucket=reduce_bucket if (self.world > 1 or (self.force_buckets and self.dist is not None)) else None)       # :77
+        hooked = self.world > 1 or (self.force_buckets and self.dist is not None)
+        # single process + grouped backward: the gradient norm is accumulated bucket by bucket beside the dX chain
+        fold_norm = self.fold_norm and not hooked and "dbr_b" in a
+        if fold_norm:
+            self.sumsq.zero_()
+        self.backward(a, after_bucket=reduce_bucket if hooked else None, sumsq=self.sumsq if fold_norm else None)       # :77
         for h in handles:
             h.wait()
-        self.sumsq.zero_()
-        ops.grad_sumsq(self.flat_g, self.sumsq)
+        if not fold_norm:
+            self.sumsq.zero_()
+            ops.grad_sumsq(self.flat_g, self.sumsq)
         if self.lazy:
             self._pending = True                 # clip + AdamW ride under the next step's forward (or finish())
             return
