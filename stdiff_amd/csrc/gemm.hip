@@ -559,19 +559,22 @@ struct DwProblem {
     int tiles_m, tiles_n, blk_end;
 };
 struct DwGroup {
-    int n, K, k_valid;
+    int n, K, k_valid, total;
     DwProblem pr[DW_MAX];
 };
 template <typename T>
 __global__ __launch_bounds__(NT, 2) void gemm_dw_group_kernel(DwGroup g) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[smem128<T>()];
+    // the grid may be smaller than the tile count (one resident block per CU, so that the input-gradient chain that
+    // runs beside this launch keeps a slot on every CU): each block then walks tiles bid, bid + grid, ...
+#pragma unroll 1
+    for (int bid = blockIdx.x; bid < g.total; bid += gridDim.x) {
     int i = 0, start = 0;
-    const int bid = blockIdx.x;
 #pragma unroll 1
     while (i + 1 < g.n && bid >= g.pr[i].blk_end) { start = g.pr[i].blk_end; ++i; }
     const DwProblem& q = g.pr[i];
     const int local = bid - start;
-    if (local >= q.tiles_m * q.tiles_n) return;
+    if (local >= q.tiles_m * q.tiles_n) continue;
     Params p;
     p.M = q.M; p.N = q.N; p.K = g.K;
     p.A = q.A; p.lda = q.lda; p.W = q.W; p.ldw = q.ldw; p.bias = nullptr;
@@ -583,6 +586,8 @@ __global__ __launch_bounds__(NT, 2) void gemm_dw_group_kernel(DwGroup g) {
     p.t_full = p.units = 0; p.ln_parts = nullptr; p.ln_nparts = 0; p.stats_out = nullptr;
     p.colsum = q.colsum;
     gemm_nt_body<T, true, true, 1, true>(p, local, smem);
+    __syncthreads();                       // the C image of this tile is read before the next tile's staging overwrites it
+    }
 }
 
 // sum of the split-K partial products in slice order (deterministic) + the full epilogue; one thread = 4 columns
@@ -2043,8 +2048,14 @@ extern "C" int stdiff_dw_group(const stdiff_dw_group_args* a, void* stream) {
         d.blk_end = end;
     }
     for (int i = a->n; i < DW_MAX; ++i) g.pr[i] = DwProblem{};
-    if (bf) hipLaunchKernelGGL(gemm_dw_group_kernel<bf16_t>, dim3(end), dim3(NT), 0, (hipStream_t)stream, g);
-    else hipLaunchKernelGGL(gemm_dw_group_kernel<float>, dim3(end), dim3(NT), 0, (hipStream_t)stream, g);
+    g.total = end;
+    // grid: one block per tile.  STDIFF_DW_GROUP_BLOCKS = n > 0 (read once) caps it (the blocks then walk the tiles):
+    // measured on the training iteration, one resident block per CU -- leaving the dX chain a slot on every CU -- is
+    // SLOWER (2.54 against 2.46 ms at H = 1024, 6.56 against 6.15 at configs[2]'s shape); 512 blocks equal the full grid
+    static const int gblocks = [] { const char* e = getenv("STDIFF_DW_GROUP_BLOCKS"); return e ? atoi(e) : 0; }();
+    const int grid = gblocks > 0 ? min(end, gblocks) : end;
+    if (bf) hipLaunchKernelGGL(gemm_dw_group_kernel<bf16_t>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(gemm_dw_group_kernel<float>, dim3(grid), dim3(NT), 0, (hipStream_t)stream, g);
     STDIFF_LAUNCH_STATUS();
     return STDIFF_OK;
 }
