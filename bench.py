@@ -185,6 +185,60 @@ def measure_hbm_kernels(eng, ws, sched, gt, mask, dtype, reps=10):
     return out
 
 
+def measure_widened_rows(dev, reps=5):
+    """SURVEY 8(f) rows, measured at BASELINE configs[1]'s matrix (20 000 spots x 1000 genes, fp32): the device loader's
+    shuffled batch (one gather launch for the (x, x_cond) pair), the pre-processing kernel, the per-gene metric passes
+    and the Spearman kernel.  HBM-bound rows report algorithmic bytes / HIP-event time against 8 TB/s; the Spearman
+    kernel is VALU-bound and reports pair compares per second.  The matrix (80 MB) fits the 256 MB Infinity Cache, so
+    the GB/s of back-to-back repetitions are upper estimates."""
+    import numpy as np
+    from stdiff_amd import ops, synth as O
+    from stdiff_amd import metrics as M
+    from stdiff_amd.process import preprocess as P
+    N, Gn, B = 20000, 1000, 2048
+    raw = torch.from_numpy(O.synth_expression(N, Gn, 4).astype(np.float32)).to(dev)
+    imp = (raw + 0.1 * torch.randn_like(raw)).clamp_min(0) + 1e-3
+    idx = torch.randperm(N, device=dev)[:B].contiguous()
+    oa, ob = torch.empty(B, Gn, device=dev), torch.empty(B, Gn, device=dev)
+    out = torch.empty_like(raw)
+
+    def timed(fn, n=reps):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) * 1e3 / n
+
+    res = {"matrix": f"{N} x {Gn} fp32"}
+    us = timed(lambda: ops.gather_rows2(raw, imp, idx, out_a=oa, out_b=ob))
+    nb = B * Gn * 4 * 4                                    # two rows read, two written per batch element
+    res["loader_shuffled_batch (stdiff_gather_rows2, 2048 cells)"] = {"bytes": nb, "us": round(us, 1), "GB/s": round(nb / us / 1e3, 1)}
+    us = timed(lambda: P.normalize_log1p_scale(raw, out=out))
+    nb = N * Gn * 4 * 2
+    res["preprocess (normalize_total + log1p + scale, stdiff_preprocess_rows)"] = {
+        "bytes": nb, "us": round(us, 1), "GB/s": round(nb / us / 1e3, 1), "frac_of_8TB/s": round(nb / us / 1e3 / 8000.0, 3)}
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        M.gene_metrics(imp, raw, spcc=False)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    res["metrics PCC / cosine / RMSE / SSIM / JS (two passes + host float64 closed forms)"] = {
+        "ms": round(ms, 2), "device_bytes": N * Gn * 4 * 2 * 2}
+    M.spearman(imp[:10000, :500].contiguous(), raw[:10000, :500].contiguous())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    M.spearman(imp, raw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res["metrics SPCC (rank by counting, stdiff_rank_corr)"] = {"ms": round(dt * 1e3, 1),
+                                                               "T_pair_compares/s": round(N * N * Gn * 2 / dt / 1e12, 2)}
+    return res
+
+
 def alt_sampling_leg(dtype, dev, lens, gt, mask, sched, row_offset, spots_total, lanes, steps, warmup):
     """The same reverse step over the same spots in another MFMA operand format (reported next to the headline)."""
     from stdiff_amd import engine as E
@@ -509,6 +563,7 @@ def main():
         if not args.no_train:
             del gt
             torch.cuda.empty_cache()
+            rec["widened_rows"] = measure_widened_rows(dev)
             rec["train"] = train_throughput(train_dtype, dev)
             # the data-parallel configuration's per-rank shape (BASELINE configs[2]: 2000 genes, hidden 2048)
             rec["train_cfg2_shape"] = train_throughput(train_dtype, dev, g=2000, h=2048, steps=10, warmup=3)
