@@ -112,19 +112,23 @@ template <typename TO>
 __global__ __launch_bounds__(256) void silu_cond_kernel(const float* __restrict__ temb, const int32_t* t_index,
                                                         const float* __restrict__ ycond, int ldy, TO* s, int lds,
                                                         int R, int H) {
-    const int hv = H >> 2;
+    // block = 4 rows at a time (one wave per row), lanes over the row's float4 pieces: no per-element 64-bit
+    // division (the flat grid-stride form spent more issue slots on i / (H/4), i % (H/4) than on the SiLU)
     const float* te = temb ? temb + (size_t)(*t_index) * H : nullptr;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)R * hv;
-         i += (size_t)gridDim.x * blockDim.x) {
-        int r = (int)(i / hv), c = (int)(i % hv) * 4;
-        f32x4 v = *(const f32x4*)(ycond + (size_t)r * ldy + c);
-        if (te) {
-            f32x4 t = *(const f32x4*)(te + c);
-            v += t;
-        }
+    const int lane = threadIdx.x & 63;
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < R; r += gridDim.x * 4) {
+        const float* yr = ycond + (size_t)r * ldy;
+        TO* sr = s + (size_t)r * lds;
+        for (int c = lane * 4; c < H; c += 256) {
+            f32x4 v = *(const f32x4*)(yr + c);
+            if (te) {
+                f32x4 t = *(const f32x4*)(te + c);
+                v += t;
+            }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
-        st4(s + (size_t)r * lds + c, v);
+            for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+            st4(sr + c, v);
+        }
     }
 }
 
@@ -341,7 +345,7 @@ extern "C" int stdiff_silu_cond(const float* temb, const int32_t* t_index, const
     if (R == 0) return STDIFF_OK;
     if (H % 4) return STDIFF_ERR_SHAPE;
     if (ldy % 4 || lds % 4 || !al16(ycond) || (temb && !al16(temb)) || ((uintptr_t)s & 7)) return STDIFF_ERR_ALIGN;
-    dim3 grid(ew_grid((size_t)R * H / 4)), block(256);
+    dim3 grid((unsigned)std::min<size_t>(((size_t)R + 3) / 4, (size_t)16384)), block(256);
     if (out_dtype == STDIFF_BF16)
         hipLaunchKernelGGL(silu_cond_kernel<bf16_t>, grid, block, 0, (hipStream_t)stream, temb, t_index, ycond, ldy,
                            (bf16_t*)s, lds, R, H);
