@@ -468,7 +468,10 @@ extern "C" int stdiff_colsum(const void* dY, int ld, int dtype, float* db, int a
 extern "C" int stdiff_grad_sumsq(const float* grads, int64_t n, float* sumsq, void* stream) {
     STDIFF_CHECK_ARG(grads && sumsq && n >= 0 && al16(grads));
     if (n == 0) return STDIFF_OK;
-    static const int sblocks = [] { const char* e = getenv("STDIFF_SUMSQ_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 4 * cu_count(); }();
+    // 2 blocks per CU: the per-bucket calls of the grouped backward run beside the latency-bound dX chain (sweep on the
+    // training iteration, H = 1024 / configs[2] shape: 1024 blocks 2.46 / 6.12 ms, 512: 2.38 / 6.08, 256: 2.37 / 6.24, 128:
+    // 2.46 / 6.78)
+    static const int sblocks = [] { const char* e = getenv("STDIFF_SUMSQ_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 2 * cu_count(); }();
     const unsigned gridx = (unsigned)std::min<size_t>(((size_t)n / 4 + 256) / 256, (size_t)sblocks);
     hipLaunchKernelGGL(sumsq_kernel, dim3(gridx), dim3(256), 0, (hipStream_t)stream, grads, n, sumsq);
     STDIFF_LAUNCH_STATUS();
