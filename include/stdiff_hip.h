@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define STDIFF_ABI_VERSION 13
+#define STDIFF_ABI_VERSION 14
 
 enum { STDIFF_F32 = 0, STDIFF_BF16 = 1 };
 
@@ -393,8 +393,17 @@ typedef struct {
 typedef struct {
     int n, C, dtype;                    /* problems, cells, operand dtype (STDIFF_F32 / STDIFF_BF16) */
     stdiff_dw_problem p[STDIFF_DW_GROUP_MAX];
+    float* sq_parts;                    /* NULL, or stdiff_dw_group_parts(g) floats, ALL overwritten with plain stores: one
+                                           per tile, the sum of squares of what the tile writes (weights and biases;
+                                           padding slots 0).  Their sum is the launch's share of clip_grad_norm_'s squared
+                                           norm (stDiff_train.py:78), taken from the accumulators instead of a pass over
+                                           the gradients; add them up with stdiff_sum_parts */
 } stdiff_dw_group_args;
 int stdiff_dw_group(const stdiff_dw_group_args* g, void* stream);
+long long stdiff_dw_group_parts(const stdiff_dw_group_args* g);       /* floats of g->sq_parts; < 0: bad arguments */
+/* *out = (accumulate ? *out : 0) + parts[0] + ... + parts[n - 1], one workgroup, a fixed summation order (the same bits on
+ * every run).  n >= 0; no reference counterpart (it finishes clip_grad_norm_'s norm, stDiff_train.py:78). */
+int stdiff_sum_parts(const float* parts, long long n, float* out, int accumulate, void* stream);
 
 /* ---------------------------------------------------------------- whole-denoiser training pass
  * The forward of stDiff_train.py:72 (DiT_stDiff.forward, stDiff_model.py:231-243, on one mini-batch = one attention
@@ -415,7 +424,7 @@ typedef struct {
     const stdiff_train_block* blocks;           /* host array [depth] */
     const float* freqs;                         /* as for stdiff_timestep_embedding */
 } stdiff_train_weights;
-struct stdiff_grad_ranges { float* sumsq; const float* lo[64]; long long count[64]; };
+struct stdiff_grad_ranges { float* sumsq; const float* lo[64]; long long count[64]; int in_group; float* parts; long long parts_count; };
 typedef struct {            /* saved by block k's forward */
     float* h; float* hmid;                      /* fp32 [C,H]: block input, after the attention branch */
     void* mod;                                  /* [C,6H] adaLN output */
@@ -460,7 +469,11 @@ typedef struct {
      * as the backward finishes each gradient bucket -- *sumsq += sum g^2 over [lo[i], lo[i] + count[i]) for bucket i of
      * stdiff_bucket_fn's numbering (depth + 2 buckets), issued on the stream that ran the bucket's last launches, so the
      * norm pass of clip_grad_norm_ (stDiff_train.py:78) hides under the input-gradient chain.  The caller zeroes *sumsq
-     * before the backward and must not use this under data parallelism (the norm is that of the REDUCED gradient). */
+     * before the backward and must not use this under data parallelism (the norm is that of the REDUCED gradient).
+     * in_group != 0 (and G % 8 == 0): no range pass at all -- every stdiff_dw_group launch of the backward leaves the
+     * squares of what it writes in its slice of `parts` (stdiff_dw_group_args.sq_parts; parts_count >=
+     * stdiff_dit_backward_parts(w) floats, else STDIFF_ERR_ARG) and a stdiff_sum_parts launch behind each group, on the
+     * group's stream, adds them to *sumsq in a fixed order; lo / count are then unused. */
     const struct stdiff_grad_ranges* grad_ranges;
 } stdiff_train_acts;
 /* side_stream (NULL = none): the adaLN projections of the forward and the weight-gradient jobs of the backward are
@@ -468,6 +481,7 @@ typedef struct {
  * under stream capture they become parallel branches of the graph.  Results do not depend on it. */
 int stdiff_dit_train_forward(const stdiff_train_weights* w, const stdiff_train_acts* a, const int64_t* t,
                              void* side_stream, void* stream);
+long long stdiff_dit_backward_parts(const stdiff_train_weights* w);   /* floats of stdiff_grad_ranges.parts; < 0: bad w */
 /* after_bucket (may be NULL) is called ON THE HOST, in order, with i = 0 (final layer), 1 .. depth (blocks depth-1 .. 0),
  * depth+1 (embedding layers) once everything that finishes that range of gradients has been enqueued on `stream`
  * (side-stream jobs joined): the data-parallel step issues the range's all-reduce from it (stDiff_train.py has no

@@ -84,7 +84,8 @@ class TrainBlockActs(C.Structure):
 
 class GradRanges(C.Structure):
     """struct stdiff_grad_ranges: the gradient-norm pass folded into the backward, one range per gradient bucket."""
-    _fields_ = [("sumsq", vp), ("lo", vp * 64), ("count", C.c_longlong * 64)]
+    _fields_ = [("sumsq", vp), ("lo", vp * 64), ("count", C.c_longlong * 64), ("in_group", i32), ("parts", vp),
+                ("parts_count", C.c_longlong)]
 
 
 class TrainActs(C.Structure):
@@ -107,7 +108,7 @@ class DwProblem(C.Structure):
 
 
 class DwGroupArgs(C.Structure):
-    _fields_ = [("n", i32), ("C", i32), ("dtype", i32), ("p", DwProblem * 8)]
+    _fields_ = [("n", i32), ("C", i32), ("dtype", i32), ("p", DwProblem * 8), ("sq_parts", vp)]
 
 
 BucketFn = C.CFUNCTYPE(None, i32, vp)
@@ -128,6 +129,8 @@ _SIGS = {
     "stdiff_gemm": (i32, [C.POINTER(GemmArgs), vp]),
     "stdiff_gemm_static_scratch": (i32, [C.POINTER(GemmArgs), vp]),
     "stdiff_dw_group": (i32, [C.POINTER(DwGroupArgs), vp]),
+    "stdiff_dw_group_parts": (C.c_longlong, [C.POINTER(DwGroupArgs)]),
+    "stdiff_sum_parts": (i32, [vp, C.c_longlong, vp, i32, vp]),
     "stdiff_transpose": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, vp]),
     "stdiff_attention_fwd": (i32, [vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp]),
     "stdiff_ln_modulate": (i32, [vp, i32, vp, vp, i32, i32, vp, i32, i32, vp, vp, i32, i32, vp]),
@@ -167,6 +170,7 @@ _SIGS = {
     "stdiff_dit_forward": (i32, [C.POINTER(DitWeights), C.POINTER(DitWorkspace), vp, vp, vp, i32, vp]),
     "stdiff_dit_train_forward": (i32, [C.POINTER(TrainWeights), C.POINTER(TrainActs), vp, vp, vp]),
     "stdiff_dit_backward": (i32, [C.POINTER(TrainWeights), C.POINTER(TrainActs), vp, BucketFn, vp, vp]),
+    "stdiff_dit_backward_parts": (C.c_longlong, [C.POINTER(TrainWeights)]),
     "stdiff_graph_begin": (i32, [vp]),
     "stdiff_graph_end": (i32, [vp, C.POINTER(vp)]),
     "stdiff_graph_launch": (i32, [vp, vp]),
@@ -195,7 +199,7 @@ def lib(fp16=False):
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.stdiff_abi_version() != 13:
+        if L.stdiff_abi_version() != 14:
             raise RuntimeError(f"{base} ABI version mismatch")
         if L.stdiff_h16_format() != int(bool(fp16)):
             raise RuntimeError(f"{base} was built with the wrong 16-bit operand format")

@@ -66,6 +66,7 @@ struct Params {
     const float* ln_parts; int ln_nparts;         // STDIFF_EPI_LN_MOD: partial row moments of `res` [M][parts][2]
     float* stats_out;                             // gate-residual epilogue: partial row moments of C [M][tiles_n][2]
     float* colsum;                                // gemm_dw_group_kernel only: sum over k of A[m][k]  (fp32 [M])
+    float* sumsq;                                 // gemm_dw_group_kernel only: the sum of squares of what the tile stores
 };
 
 __device__ __forceinline__ void tile_of(int bid, int nblk, int tiles_m, int tiles_n, int& tm, int& tn) {
@@ -494,6 +495,29 @@ __device__ __forceinline__ void gemm_nt_body(const Params& p, const int bid, uns
         }
     }
 
+    if constexpr (GROUPED) {
+        if (p.sumsq) {
+            // the tile's share of the squared gradient norm, from the accumulators: wave sums into the 16 bytes behind the
+            // tile buffers, one plain store per tile after the barrier below (atomics on one cell were tried first:
+            // 18 000 of them per launch at H = 2048 serialise at ~6 ns each and made the launch 160 -> 269 us)
+            float ss = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int gm = m0 + wm * 64 + mt * 16 + fr;
+                float rs = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int gn = n0 + wn * 64 + nt * 16 + fq * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rs += gn + e < p.N ? acc[mt][nt][e] * acc[mt][nt][e] : 0.f;
+                }
+                if (colsum && fq == 0) rs += accb[mt][0] * accb[mt][0];
+                ss += gm < p.M ? rs : 0.f;
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) ((float*)(smem + smem128<T>()))[wid] = ss;
+        }
+    }
     // ---- accumulators -> fp32 C image in LDS (lane holds 4 consecutive n of one m)
     float* cl = (float*)smem;
 #pragma unroll
@@ -511,6 +535,10 @@ __device__ __forceinline__ void gemm_nt_body(const Params& p, const int bid, uns
                 const int gm = m0 + wm * 64 + mt * 16 + fr;
                 if (gm < p.M) p.colsum[gm] = accb[mt][0];
             }
+        }
+        if (p.sumsq && tid == 0) {
+            const float* sq = (const float*)(smem + smem128<T>());
+            *p.sumsq = (sq[0] + sq[1]) + (sq[2] + sq[3]);
         }
         epi_rows128<STDIFF_EPI_BIAS, T>(p, cl, tid, m0, n0);
         return;
@@ -560,11 +588,12 @@ struct DwProblem {
 };
 struct DwGroup {
     int n, K, k_valid, total;
+    float* sumsq;
     DwProblem pr[DW_MAX];
 };
 template <typename T>
 __global__ __launch_bounds__(NT, 2) void gemm_dw_group_kernel(DwGroup g) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[smem128<T>()];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[smem128<T>() + 16];      // + four wave sums (g.sumsq)
     // the grid may be smaller than the tile count (one resident block per CU, so that the input-gradient chain that
     // runs beside this launch keeps a slot on every CU): each block then walks tiles bid, bid + grid, ...
 #pragma unroll 1
@@ -574,7 +603,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_dw_group_kernel(DwGroup g) {
     while (i + 1 < g.n && bid >= g.pr[i].blk_end) { start = g.pr[i].blk_end; ++i; }
     const DwProblem& q = g.pr[i];
     const int local = bid - start;
-    if (local >= q.tiles_m * q.tiles_n) continue;
+    if (local >= q.tiles_m * q.tiles_n) {          // padding block: its slots of the squared-norm parts are zero
+        if (g.sumsq && threadIdx.x == 0) g.sumsq[bid] = 0.f;
+        continue;
+    }
     Params p;
     p.M = q.M; p.N = q.N; p.K = g.K;
     p.A = q.A; p.lda = q.lda; p.W = q.W; p.ldw = q.ldw; p.bias = nullptr;
@@ -584,7 +616,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_dw_group_kernel(DwGroup g) {
     p.tiles_m = q.tiles_m; p.tiles_n = q.tiles_n; p.k_valid = g.k_valid;
     p.ksplit = 1; p.nk_per = g.K / Cfg<T>::BK; p.ws = nullptr; p.ldws = 0;
     p.t_full = p.units = 0; p.ln_parts = nullptr; p.ln_nparts = 0; p.stats_out = nullptr;
-    p.colsum = q.colsum;
+    p.colsum = q.colsum; p.sumsq = g.sumsq ? g.sumsq + bid : nullptr;
     gemm_nt_body<T, true, true, 1, true>(p, local, smem);
     __syncthreads();                       // the C image of this tile is read before the next tile's staging overwrites it
     }
@@ -1884,7 +1916,7 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
     p.C = a->C; p.ldc = a->ldc; p.c_bf16 = a->c_dtype == STDIFF_BF16;
     p.epi = a->epi; p.gate = a->gate; p.ldgate = a->ldgate; p.res = a->res; p.ldres = a->ldres;
     p.C2 = a->C2; p.ldc2 = a->ldc2;
-    p.ln_parts = a->ln_parts; p.ln_nparts = a->ln_nparts; p.stats_out = a->stats_out; p.colsum = nullptr;
+    p.ln_parts = a->ln_parts; p.ln_nparts = a->ln_nparts; p.stats_out = a->stats_out; p.colsum = nullptr; p.sumsq = nullptr;
     // 4-wide pieces: fp32 needs 16-byte, bf16 8-byte alignment of every row piece
     bool vec = a->N % 8 == 0 && a->ldc % 4 == 0 && (p.c_bf16 ? al8(a->C) : al16(a->C)) && (!a->bias || al16(a->bias));
     if (a->epi == STDIFF_EPI_GATE_RES)
@@ -2025,15 +2057,35 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
 }
 }  // namespace
 
+// floats of stdiff_dw_group_args.sq_parts the launch writes: one per block of the grid before any cap
+extern "C" long long stdiff_dw_group_parts(const stdiff_dw_group_args* a) {
+    if (!a || a->n < 1 || a->n > STDIFF_DW_GROUP_MAX) return -1;
+    long long end = 0;
+    for (int i = 0; i < a->n; ++i) {
+        if (a->p[i].M <= 0 || a->p[i].N <= 0) return -1;
+        end += ((long long)cdiv(a->p[i].M, BM) * cdiv(a->p[i].N, BN) + 7) & ~7LL;
+    }
+    return end;
+}
+
 // The weight gradients of several linear layers over one batch, one launch (gemm_dw_group_kernel).
 extern "C" int stdiff_dw_group(const stdiff_dw_group_args* a, void* stream) {
     STDIFF_CHECK_ARG(a != nullptr && a->n >= 1 && a->n <= STDIFF_DW_GROUP_MAX && a->C >= 0);
     STDIFF_CHECK_ARG(a->dtype == STDIFF_F32 || a->dtype == STDIFF_BF16);
-    if (a->C == 0) return STDIFF_OK;
+    if (a->sq_parts && ((uintptr_t)a->sq_parts & 3)) return STDIFF_ERR_ALIGN;
+    if (a->C == 0) {
+        if (a->sq_parts) {
+            const long long n = stdiff_dw_group_parts(a);
+            STDIFF_CHECK_ARG(n >= 0);
+            const hipError_t e = hipMemsetAsync(a->sq_parts, 0, (size_t)n * 4, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+        }
+        return STDIFF_OK;
+    }
     const bool bf = a->dtype == STDIFF_BF16;
     const int bk = bf ? 64 : 16, epv = bf ? 8 : 4;
     DwGroup g;
-    g.n = a->n; g.k_valid = a->C; g.K = (a->C + bk - 1) / bk * bk;
+    g.n = a->n; g.k_valid = a->C; g.K = (a->C + bk - 1) / bk * bk; g.sumsq = a->sq_parts;
     int end = 0;
     for (int i = 0; i < a->n; ++i) {
         const stdiff_dw_problem& q = a->p[i];

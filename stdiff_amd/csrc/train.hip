@@ -204,6 +204,22 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, int64_t n, f
     if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1]) + (part[2] + part[3]));
 }
 
+// out (+)= sum of parts[0 .. n): one workgroup, thread t adds elements t, t + 1024, ... in order, then a fixed tree
+__global__ __launch_bounds__(1024) void sum_parts_kernel(const float* parts, int64_t n, float* out, int accumulate) {
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) acc += parts[i];
+    acc = wave_sum(acc);
+    __shared__ float part[16];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += part[i];
+        *out = accumulate ? *out + t : t;
+    }
+}
+
 // torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW, one pass: 16 B read of p,g,m,v, 12 B write -> 28 B/param
 __global__ void adam_prep_kernel(const float* sumsq, int32_t* step_dev, float* scal, float max_norm, float gscale,
                                  float lr, float b1, float b2) {
@@ -474,6 +490,13 @@ extern "C" int stdiff_grad_sumsq(const float* grads, int64_t n, float* sumsq, vo
     static const int sblocks = [] { const char* e = getenv("STDIFF_SUMSQ_BLOCKS"); return e && atoi(e) > 0 ? atoi(e) : 2 * cu_count(); }();
     const unsigned gridx = (unsigned)std::min<size_t>(((size_t)n / 4 + 256) / 256, (size_t)sblocks);
     hipLaunchKernelGGL(sumsq_kernel, dim3(gridx), dim3(256), 0, (hipStream_t)stream, grads, n, sumsq);
+    STDIFF_LAUNCH_STATUS();
+    return STDIFF_OK;
+}
+
+extern "C" int stdiff_sum_parts(const float* parts, long long n, float* out, int accumulate, void* stream) {
+    STDIFF_CHECK_ARG(out && n >= 0 && (parts || n == 0));
+    hipLaunchKernelGGL(sum_parts_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, parts, (int64_t)n, out, accumulate);
     STDIFF_LAUNCH_STATUS();
     return STDIFF_OK;
 }

@@ -8,6 +8,8 @@
 // projections (functions of SiLU(c) alone) go there as one chain.  Fork / join use a small pool of HIP events that the
 // library creates once per device (events hold no device memory); under stream capture they become graph edges.
 // No device memory is allocated here; every buffer comes from the caller.  Not thread-safe per device.
+#include <initializer_list>
+#include <utility>
 #include <mutex>
 
 #include "common.h"
@@ -160,8 +162,30 @@ struct Ctx {
         return STDIFF_OK;
     }
     // gradient-norm contribution of bucket i (stdiff_train_acts.grad_ranges), on the stream that finished the bucket
+    // in_group: the weight-gradient groups leave the squares of what they write in slices of grad_ranges->parts (no
+    // pass over the gradients); sum_parts() adds them to *sumsq once the last group has been joined
+    bool norm_in_group() const { return a->grad_ranges && a->grad_ranges->sumsq && a->grad_ranges->in_group && w->G % 8 == 0; }
+    long long parts_used = 0, parts_last = 0;
+    int take_parts(stdiff_dw_group_args& g) {
+        if (!norm_in_group() || a->grad_ranges->in_group == 2) return STDIFF_OK;      // 2: timing probe, no norm at all
+        const long long n = stdiff_dw_group_parts(&g);
+        STDIFF_CHECK_ARG(n >= 0 && a->grad_ranges->parts && parts_used + n <= a->grad_ranges->parts_count);
+        g.sq_parts = a->grad_ranges->parts + parts_used;
+        parts_last = n;
+        parts_used += n;
+        return STDIFF_OK;
+    }
+    // *sumsq += the parts of the group launched last, on that group's stream (groups run in stream order on the side
+    // stream, the embedding layers' group after the join: one fixed summation order)
+    int sum_parts(bool on_side) {
+        if (parts_last == 0) return STDIFF_OK;
+        const long long n = parts_last;
+        parts_last = 0;
+        return stdiff_sum_parts(a->grad_ranges->parts + parts_used - n, n, a->grad_ranges->sumsq, 1, st(on_side));
+    }
     int norm(bool on_side, int bucket) const {
         const stdiff_grad_ranges* r = a->grad_ranges;
+        if (norm_in_group()) return STDIFF_OK;
         if (!r || !r->sumsq || bucket < 0 || bucket >= 64 || !r->lo[bucket] || r->count[bucket] <= 0) return STDIFF_OK;
         return stdiff_grad_sumsq(r->lo[bucket], r->count[bucket], r->sumsq, st(on_side));
     }
@@ -253,8 +277,10 @@ int backward_grouped(Ctx& c, stdiff_bucket_fn after_bucket, void* user) {
         g.p[g.n++] = Ctx::prob(w->fada, 2 * H, H, a->dfmod, 2 * H, a->s, H);
         if (!odd_genes) g.p[g.n++] = Ctx::prob(w->out, G, H, a->deps, Gp, a->xnf, H);
         // d loss / d s accumulates over all adaLN projections on the stream that runs the groups, in issue order
+        TRY(c.take_parts(g));
         TRY(c.group(g, [&](bool sd) {
             TRY(c.norm(sd, 0));
+            TRY(c.sum_parts(sd));
             return c.dX(sd, C, a->dfmod, 2 * H, 2 * H, w->fada, 2 * H, H, a->ds32, H, STDIFF_F32);
         }));
     }
@@ -295,8 +321,10 @@ int backward_grouped(Ctx& c, stdiff_bucket_fn after_bucket, void* user) {
         g.p[g.n++] = Ctx::prob(b.fc2, H, 4 * H, dbrm[q], H, s.u, 4 * H);
         g.p[g.n++] = Ctx::prob(b.qkv, 3 * H, H, dqkv[q], 3 * H, s.xn1, H);
         g.p[g.n++] = Ctx::prob(b.proj, H, H, dbra[q], H, s.o, H);
+        TRY(c.take_parts(g));
         TRY(c.group(g, [&](bool sd) {
             TRY(c.norm(sd, D - k));
+            TRY(c.sum_parts(sd));
             return c.dX(sd, C, dmod, 6 * H, 6 * H, b.ada, 6 * H, H, a->ds32, H, STDIFF_F32, STDIFF_EPI_ACCUM);
         }));
     }
@@ -317,12 +345,14 @@ int backward_grouped(Ctx& c, stdiff_bucket_fn after_bucket, void* user) {
             g.p[g.n++] = Ctx::prob(w->in, H, G, a->dhT, H, a->xp, Gp);
             g.p[g.n++] = Ctx::prob(w->cond, H, G, a->dcT, H, a->yp, Gp);
         }
+        TRY(c.take_parts(g));
         TRY(stdiff_dw_group(&g, stream));
         if (odd_genes) {
             TRY(c.dW_enqueue(false, w->in, H, G, a->dhT, H, H, a->xp, Gp, Gp));
             TRY(c.dW_enqueue(false, w->cond, H, G, a->dcT, H, H, a->yp, Gp, Gp));
         }
         TRY(c.norm(false, D + 1));
+        TRY(c.sum_parts(false));
     }
     if (after_bucket) after_bucket(D + 1, user);
     return STDIFF_OK;
@@ -413,6 +443,20 @@ extern "C" int stdiff_dit_train_forward(const stdiff_train_weights* w, const std
 // overwritten.  after_bucket(i, user), when given, is called on the host when the launches that finish the i-th
 // gradient range (final layer; block depth-1 .. 0; embedding layers) have been enqueued on `stream` -- the
 // data-parallel step issues that range's all-reduce from it.
+// floats of stdiff_grad_ranges.parts that backward_grouped() hands to its stdiff_dw_group launches (same groups, same order)
+extern "C" long long stdiff_dit_backward_parts(const stdiff_train_weights* w) {
+    if (!w || w->H <= 0 || w->G <= 0 || w->depth < 0 || w->depth > MAX_DEPTH) return -1;
+    if (w->G % 8 != 0) return 0;
+    const int H = w->H, G = w->G;
+    auto parts = [](std::initializer_list<std::pair<int, int>> mn) {
+        stdiff_dw_group_args g = {};
+        for (auto& q : mn) { g.p[g.n].M = q.first; g.p[g.n].N = q.second; ++g.n; }
+        return stdiff_dw_group_parts(&g);
+    };
+    return parts({{2 * H, H}, {G, H}}) + w->depth * parts({{6 * H, H}, {4 * H, H}, {H, 4 * H}, {3 * H, H}, {H, H}}) +
+           parts({{H, H}, {H, 256}, {H, G}, {H, G}});
+}
+
 extern "C" int stdiff_dit_backward(const stdiff_train_weights* w, const stdiff_train_acts* a, void* side_stream,
                                    stdiff_bucket_fn after_bucket, void* user, void* stream) {
     TRY(check_common(w, a));

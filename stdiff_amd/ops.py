@@ -70,10 +70,7 @@ def gemm(A, W, bias=None, out=None, out_dtype=None, epi=L.EPI_BIAS, gate=None, r
     return out
 
 
-def dw_group(problems, C_rows=None):
-    """One launch for several weight gradients over the same batch: for each (dY, X, gw, gb[, M]) in `problems`
-    gw[M, N] = dY[:, :M]^T X[:, :N] and gb[M] = colsum(dY[:, :M]) (gb may be None).  dY [C, >= M], X [C, >= N] of the
-    operand dtype, gw / gb fp32, overwritten."""
+def _dw_group_args(problems, C_rows):
     a = L.DwGroupArgs()
     assert 1 <= len(problems) <= 8
     first = problems[0][0]
@@ -88,7 +85,37 @@ def dw_group(problems, C_rows=None):
         assert dY.shape[1] >= q.M and X.shape[1] >= q.N
         q.dY, q.lddy, q.X, q.ldx = ptr(dY), dY.stride(0), ptr(X), X.stride(0)
         q.gw, q.ldgw, q.gb = ptr(gw), gw.stride(0), ptr(gb)
+    return a, first
+
+
+def dw_group_parts(problems, C_rows=None):
+    """Number of floats dw_group(problems, sq_parts=...) writes."""
+    a, first = _dw_group_args(problems, C_rows)
+    n = lib_for(first).stdiff_dw_group_parts(C.byref(a))
+    if n < 0:
+        raise ValueError("stdiff_dw_group_parts: bad problem list")
+    return int(n)
+
+
+def dw_group(problems, C_rows=None, sq_parts=None):
+    """One launch for several weight gradients over the same batch: for each (dY, X, gw, gb[, M]) in `problems`
+    gw[M, N] = dY[:, :M]^T X[:, :N] and gb[M] = colsum(dY[:, :M]) (gb may be None).  dY [C, >= M], X [C, >= N] of the
+    operand dtype, gw / gb fp32, overwritten.  sq_parts (fp32 [>= dw_group_parts(problems)], optional): overwritten with
+    per-wave sums of squares of everything written -- their sum is the launch's squared gradient norm (sum_parts)."""
+    a, first = _dw_group_args(problems, C_rows)
+    if sq_parts is not None:
+        require_gpu(sq_parts)
+        n = lib_for(first).stdiff_dw_group_parts(C.byref(a))
+        assert sq_parts.dtype == torch.float32 and sq_parts.is_contiguous() and 0 <= n <= sq_parts.numel()
+        a.sq_parts = ptr(sq_parts)
     check(lib_for(first).stdiff_dw_group(C.byref(a), stream()))
+
+
+def sum_parts(parts, out, accumulate=True):
+    """out[0] (+)= parts.sum(), one workgroup, fixed order (the same bits every run)."""
+    require_gpu(parts, out)
+    assert parts.dtype == torch.float32 and out.dtype == torch.float32 and parts.is_contiguous()
+    check(lib().stdiff_sum_parts(ptr(parts), parts.numel(), ptr(out), int(accumulate), stream()))
 
 
 def transpose(x, out=None, rows_pad=None):

@@ -104,7 +104,11 @@ class TrainCore:
         # forward / backward, attention backward) instead of paying a reduce launch (STDIFF_TRAIN_DEFER=0: A/B timing;
         # results are bit-identical either way)
         self.defer = os.environ.get("STDIFF_TRAIN_DEFER", "1") != "0"
+        # the folded gradient norm (backward(sumsq=...)) comes from the group launches' accumulators
+        # (STDIFF_TRAIN_NORM_IN_GROUP=0: one stdiff_grad_sumsq pass per bucket beside the chain, A/B timing)
+        self.norm_in_group = os.environ.get("STDIFF_TRAIN_NORM_IN_GROUP", "1") != "0"
         self._cw = None
+        self._parts = None
 
     def refresh_weights(self, pack=True):
         """fp32 master weights -> packed MFMA operands (the backward reads the same [out, in] copies K-major)."""
@@ -381,15 +385,21 @@ class TrainCore:
                        w_kmajor=True, side=side)
         ops.colsum(dY[:, :m] if rows is not None else dY, self.g[name + ".bias"])
 
-    def _group(self, problems, then=None):
+    def _group(self, problems, then=None, parts=None):
         """[(name, dY, X[, rows])]: every weight / bias gradient of the list in ONE launch (ops.dw_group), forked like
         _dW but not joined: backward() calls _side_join() where the group's buffers are first rewritten."""
         pr = []
         for item in problems:
             name, dY, X = item[:3]
             pr.append((dY, X, self.g[name + ".weight"], self.g[name + ".bias"], item[3] if len(item) > 3 else None))
+        sumsq = None
+        if parts is not None:                       # [buffer, floats used, start of the last slice]: this launch's slice
+            n = ops.dw_group_parts(pr)
+            sumsq = parts[0][parts[1]:parts[1] + n]
+            assert sumsq.numel() == n
+            parts[2], parts[1] = parts[1], parts[1] + n
         if not self._side_on:
-            ops.dw_group(pr)
+            ops.dw_group(pr, sq_parts=sumsq)
             if then is not None:
                 then(False)
             return
@@ -398,12 +408,20 @@ class TrainCore:
         ready.record(cur)
         self._side.wait_event(ready)
         with torch.cuda.stream(self._side):
-            ops.dw_group(pr)
+            ops.dw_group(pr, sq_parts=sumsq)
             if then is not None:
                 then(True)
             done = torch.cuda.Event()
             done.record(self._side)
         self._side_prev = done
+
+    def _norm_parts(self):
+        """The buffer the group launches leave their squared-norm parts in (stdiff_grad_ranges.parts)."""
+        if self._parts is None:
+            n = int(L.lib().stdiff_dit_backward_parts(self._c_weights()))
+            assert n >= 0
+            self._parts = torch.zeros(max(n, 4), dtype=torch.float32, device=self.device)
+        return self._parts
 
     def _backward_grouped(self, a, after_bucket):
         """The launch sequence of backward_grouped() in csrc/train_engine.hip, issued from Python."""
@@ -431,15 +449,21 @@ class TrainCore:
         first = [("out_layer.adaLN_modulation.1", a["dfmod"], a["s"])]
         if not odd:
             first.append(("out_layer.linear", deps, a["xnf"], G))
+        # the squared gradient norm: added by the group launches themselves (norm_in_group), else one pass per bucket
+        in_group = self._norm is not None and self.norm_in_group and not odd
+        gsq = [self._norm_parts(), 0, 0] if in_group else None
+
         def norm(i):
-            if self._norm is not None:
+            if in_group:                               # the parts of the group launched last, on its stream
+                ops.sum_parts(gsq[0][gsq[2]:gsq[1]], self._norm[0])
+            elif self._norm is not None:
                 lo, hi = self._norm[1][i]
                 ops.grad_sumsq(self.flat_g[lo:hi], self._norm[0])
 
         def then_first(sd):
             norm(0)
             self._dX("out_layer.adaLN_modulation.1", a["dfmod"], a["ds32"], side=sd)
-        self._group(first, then=then_first)
+        self._group(first, then=then_first, parts=gsq)
         for k in range(D - 1, -1, -1):
             p, q = f"blks.{k}.", k & 1
             mod, dmod = a["mod"][k], a["dmod"][q]
@@ -472,7 +496,8 @@ class TrainCore:
                          (p + "attn.proj", dbra[q], a["o"][k])],
                         then=lambda sd, p=p, dmod=dmod, k=k: (norm(D - k),
                                                               self._dX(p + "adaLN_modulation.1", dmod, a["ds32"],
-                                                                       epi=L.EPI_ACCUM, side=sd)))
+                                                                       epi=L.EPI_ACCUM, side=sd)),
+                        parts=gsq)
         self._side_join()
         if after_bucket:
             after_bucket(D)
@@ -485,7 +510,7 @@ class TrainCore:
         last = [("time_emb.mlp.2", a["dcT_"], a["e1"]), ("time_emb.mlp.0", a["da1"], a["e0"])]
         if not odd:
             last += [("in_layer.0", a["dhT_"], a["xp"]), ("cond_layer.0", a["dcT_"], a["yp"])]
-        self._group(last)
+        self._group(last, parts=gsq)
         if odd:
             self._dW_enqueue(a, "in_layer.0", a["dhT_"], a["xp"], None, False)
             self._dW_enqueue(a, "cond_layer.0", a["dcT_"], a["yp"], None, False)
@@ -516,6 +541,10 @@ class TrainCore:
                 gr.sumsq = L.ptr(sumsq)
                 for i, (lo, hi) in enumerate(self._norm[1]):
                     gr.lo[i], gr.count[i] = L.ptr(self.flat_g) + 4 * lo, hi - lo
+                gr.in_group = int(os.environ.get("STDIFF_TRAIN_NORM_IN_GROUP", "1"))
+                if gr.in_group and self.G % 8 == 0:
+                    parts = self._norm_parts()
+                    gr.parts, gr.parts_count = L.ptr(parts), parts.numel()
                 a["_grad_ranges"] = gr
                 ca.grad_ranges = L.C.pointer(gr)
             else:

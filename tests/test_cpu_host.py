@@ -26,8 +26,8 @@ def test_library_exports_every_declared_symbol():
     lib16 = ctypes.CDLL(_lib.LIB_PATH_F16)           # the fp16 build: same entry points
     assert not [s for s in sorted(declared) if not hasattr(lib16, s)]
     L = _lib.lib()
-    assert L.stdiff_abi_version() == 13 and L.stdiff_h16_format() == 0
-    assert _lib.lib(True).stdiff_abi_version() == 13 and _lib.lib(True).stdiff_h16_format() == 1
+    assert L.stdiff_abi_version() == 14 and L.stdiff_h16_format() == 0
+    assert _lib.lib(True).stdiff_abi_version() == 14 and _lib.lib(True).stdiff_h16_format() == 1
     assert b"aligned" in L.stdiff_error_string(-3)
 
 

@@ -209,12 +209,30 @@ def test_dw_group_against_fp32(ops, L, dt, C):
         refs.append((q(dY, dt)[:, :M].T @ q(X, dt)[:, :N], q(dY, dt)[:, :M].sum(0)))
     ops.dw_group(prob)
     tol = 3e-6 if dt == "fp32" else 3e-5
+    total = 0.0
     for (dY, X, gw, gb, M), (rw, rb) in zip(prob, refs):
         assert relerr(gw, rw) < tol
         one = ops.gemm(dY, X[:, :gw.shape[1]], None, out_dtype=torch.float32, a_kmajor=True, w_kmajor=True, M=M)
         assert relerr(gw, one) < tol
+        total += float(gw.double().pow(2).sum())
         if gb is not None:
             assert relerr(gb, rb) < tol
+            total += float(gb.double().pow(2).sum())
+    # the launch's share of the squared gradient norm (args.sq_parts): per-wave sums of squares of everything it wrote,
+    # ragged edges excluded, every slot overwritten; stdiff_sum_parts adds them in a fixed order
+    kept = [(gw.clone(), None if gb is None else gb.clone()) for _, _, gw, gb, _ in prob]
+    n = ops.dw_group_parts(prob)
+    parts = torch.full((n + 8,), float("nan"), device=DEV)
+    ops.dw_group(prob, sq_parts=parts[:n])
+    assert bool(torch.isfinite(parts[:n]).all()) and bool(torch.isnan(parts[n:]).all())
+    ss = torch.full((1,), 3.0, device=DEV)
+    ops.sum_parts(parts[:n], ss)
+    assert abs(float(ss) - 3.0 - total) < 2e-6 * total
+    again = torch.empty(1, device=DEV)
+    ops.sum_parts(parts[:n], again, accumulate=False)
+    assert abs(float(again) - total) < 2e-6 * total and abs(float(again) - float(parts[:n].double().sum())) < 1e-6 * total
+    for (_, _, gw, gb, _), (kw, kb) in zip(prob, kept):
+        assert torch.equal(gw, kw) and (gb is None or torch.equal(gb, kb))
     with pytest.raises((ValueError, RuntimeError)):          # 16-byte column pieces do not exist for 33 columns
         ops.dw_group([(prob[0][0], prob[0][1], torch.zeros(33, 128, device=DEV), None, 33)])
 
