@@ -412,9 +412,14 @@ extern "C" int stdiff_dit_train_forward(const stdiff_train_weights* w, const std
         float* h_next = k + 1 < D ? a->blocks[k + 1].h : a->h_last;
         STDIFF_CHECK_ARG(s.h && s.hmid && s.mod && s.xn1 && s.xn2 && s.qkv && s.o && s.lse && s.pa && s.pm && s.upre &&
                          s.u && s.mean1 && s.rstd1 && s.mean2 && s.rstd2);
-        TRY(ready(c.main, 1 + k));
-        if (fork) TRYH(hipStreamWaitEvent(c.main, c.ev[3 + k], 0));
-        else TRY(c.lin(false, C, 6 * H, H, a->s, H, b.ada, H, s.mod, 6 * H, dt));
+        // with the side stream, mod[k]'s event already orders this stream behind param_ready[1 + k] (the side stream waited
+        // for it before the adaLN GEMM): a second cross-stream edge per block would only cost its latency
+        if (fork) {
+            TRYH(hipStreamWaitEvent(c.main, c.ev[3 + k], 0));
+        } else {
+            TRY(ready(c.main, 1 + k));
+            TRY(c.lin(false, C, 6 * H, H, a->s, H, b.ada, H, s.mod, 6 * H, dt));
+        }
         TRY(c.ln(pend, s.h, H, col(s.mod, dt, 0), col(s.mod, dt, H), 6 * H, s.xn1, s.mean1, s.rstd1));
         TRY(c.lin(false, C, 3 * H, H, s.xn1, H, b.qkv, H, s.qkv, 3 * H, dt));
         TRY(stdiff_attention_fwd(s.qkv, 3 * H, s.o, H, s.lse, a->cu_rows, 1, C, w->heads, d, dt, stream));
@@ -432,9 +437,12 @@ extern "C" int stdiff_dit_train_forward(const stdiff_train_weights* w, const std
         TRY(c.lin(false, C, H, 4 * H, s.u, 4 * H, b.fc2, 4 * H, h_next, H, STDIFF_F32, STDIFF_EPI_GATE_RES,
                   col(s.mod, dt, 5 * H), 6 * H, s.hmid, H, s.pm, H, fork ? &pend.sp : nullptr));
     }
-    TRY(ready(c.main, 1 + D));
-    if (fork) TRYH(hipStreamWaitEvent(c.main, c.ev[3 + D], 0));
-    else TRY(c.lin(false, C, 2 * H, H, a->s, H, w->fada, H, a->fmod, 2 * H, dt));
+    if (fork) {
+        TRYH(hipStreamWaitEvent(c.main, c.ev[3 + D], 0));
+    } else {
+        TRY(ready(c.main, 1 + D));
+        TRY(c.lin(false, C, 2 * H, H, a->s, H, w->fada, H, a->fmod, 2 * H, dt));
+    }
     TRY(c.ln(pend, a->h_last, H, col(a->fmod, dt, 0), col(a->fmod, dt, H), 2 * H, a->xnf, a->meanf, a->rstdf));
     return c.lin(false, C, G, H, a->xnf, H, w->out, H, a->eps, G, STDIFF_F32);
 }

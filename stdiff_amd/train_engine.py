@@ -309,8 +309,8 @@ class TrainCore:
         for k in range(D):
             p = f"blks.{k}."
             mod = a["mod"][k]
-            params_ready(1 + k)
-            if mod_ready is None:
+            if mod_ready is None:             # (else mod_ready[k] already orders this stream behind param_ready[1 + k])
+                params_ready(1 + k)
                 w, b = self._lin(p + "adaLN_modulation.1")
                 g(a["s"], w, b, out=mod)
             else:
@@ -332,8 +332,8 @@ class TrainCore:
             pend = dict(split=sr(mod_ready is not None), bias=b, gate=mod[:, 5 * H:6 * H], res=a["hmid"][k], v_out=a["pm"][k])
             g(a["u"][k], w, b, out=a["h"][k + 1], epi=L.EPI_GATE_RES, gate=mod[:, 5 * H:6 * H], res=a["hmid"][k], out2=a["pm"][k],
               defer=pend["split"])
-        params_ready(1 + D)
         if mod_ready is None:
+            params_ready(1 + D)
             w, b = self._lin("out_layer.adaLN_modulation.1")
             g(a["s"], w, b, out=a["fmod"])
         else:
