@@ -818,3 +818,35 @@ def test_lazy_update_equals_eager_update(dtype, use_graph, enqueue, monkeypatch)
     tol = 1e-4 if dtype == "fp32" else 2e-2
     for k in (1, 2, 3):
         assert relerr(res[True][k], res[False][k]) < tol, k
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_training_iterations_repeat_bit_for_bit(dtype):
+    """With the squared gradient norm taken from the weight-gradient accumulators (stdiff_dw_group_args.sq_parts, summed by
+    stdiff_sum_parts in a fixed order) nothing in an iteration depends on the order in which workgroups finish: two runs
+    from the same seeds give the same parameters, moments and gradient norms, bit for bit (the loss VALUE is still summed
+    with float atomics and is compared loosely)."""
+    from stdiff_amd.train_engine import TrainEngine
+    G, H, depth, heads, T, C = 72, 128, 3, 4, 1000, 96
+    mask = O.kfold_mask(G, 1)
+    x = torch.from_numpy((O.synth_expression(C, G, 9) * 2 - 1).astype(np.float32)).to(DEV)
+    xc = (x * torch.from_numpy(mask).to(DEV)).float()
+    runs = []
+    for _ in range(2):
+        m, _ = build(G, H, depth, heads, 71, dtype)
+        te = TrainEngine(m, lr=1e-3, diffusion_step=T, mask=mask, lazy_update=True)
+        assert te.fold_norm and te.norm_in_group
+        gen = torch.Generator().manual_seed(5)
+        norms, losses = [], []
+        for i in range(6):
+            noise = torch.randn(C, G, generator=gen).to(DEV)
+            tt = torch.randint(1, T, (C,), generator=gen).to(DEV)
+            loss, _ = te.step(x, xc, noise=noise, timesteps=tt, use_graph=True)
+            losses.append(float(loss))
+            norms.append(float(te.sumsq))
+        te.finish()
+        runs.append((te.flat_p.clone(), te.m.clone(), te.v.clone(), norms, losses))
+    a, b = runs
+    assert a[3] == b[3] and all(n > 0 for n in a[3])
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert all(abs(p - q) < 1e-5 * abs(q) for p, q in zip(a[4], b[4]))
