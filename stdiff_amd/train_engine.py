@@ -647,8 +647,10 @@ class TrainEngine(TrainCore):
         self.v = torch.zeros_like(self.flat_p)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.scal = torch.zeros(4, dtype=torch.float32, device=dev)
-        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        # loss and squared gradient norm side by side: one fill launch zeroes both (they start at zero at the same point of
+        # an iteration, between the forward and the loss)
+        self._cells = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.loss, self.sumsq = self._cells[0:1], self._cells[1:2]
         self.pg = process_group
         self.dist = None
         self.world = 1
@@ -753,7 +755,13 @@ class TrainEngine(TrainCore):
         if ready is not None:
             a["_ready_events"] = (self._fork_event, ready)      # a captured graph keeps its events alive
             torch.cuda.current_stream().wait_event(ready[-1])      # the update has read every gradient
-        self.loss.zero_()
+        hooked = self.world > 1 or (self.force_buckets and self.dist is not None)
+        # single process + grouped backward: the gradient norm is accumulated inside the backward
+        fold_norm = self.fold_norm and not hooked and "dbr_b" in a
+        if fold_norm:
+            self._cells.zero_()                  # loss and sumsq
+        else:
+            self.loss.zero_()
         ops.masked_mse(eps, noise, self.mask, self.loss, dp=a["deps"])                 # :75 (+ d loss / d eps)
         handles = []
 
@@ -764,11 +772,6 @@ class TrainEngine(TrainCore):
             else:
                 torch.cuda.synchronize(self.device)      # gloo + CUDA tensors behind a busy stream stalled on this stack
                 self.dist.all_reduce(self.flat_g[lo:hi], group=self.pg)
-        hooked = self.world > 1 or (self.force_buckets and self.dist is not None)
-        # single process + grouped backward: the gradient norm is accumulated bucket by bucket beside the dX chain
-        fold_norm = self.fold_norm and not hooked and "dbr_b" in a
-        if fold_norm:
-            self.sumsq.zero_()
         self.backward(a, after_bucket=reduce_bucket if hooked else None, sumsq=self.sumsq if fold_norm else None)       # :77
         for h in handles:
             h.wait()
