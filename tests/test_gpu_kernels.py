@@ -233,6 +233,14 @@ def test_dw_group_against_fp32(ops, L, dt, C):
     assert abs(float(again) - total) < 2e-6 * total and abs(float(again) - float(parts[:n].double().sum())) < 1e-6 * total
     for (_, _, gw, gb, _), (kw, kb) in zip(prob, kept):
         assert torch.equal(gw, kw) and (gb is None or torch.equal(gb, kb))
+    # no cells: the parts are still all written (zeros); an empty parts list leaves / clears the cell
+    parts.fill_(float("nan"))
+    ops.dw_group(prob, C_rows=0, sq_parts=parts[:n])
+    assert float(parts[:n].abs().sum()) == 0.0 and bool(torch.isnan(parts[n:]).all())
+    ops.sum_parts(parts[:0], ss)
+    assert abs(float(ss) - 3.0 - total) < 2e-6 * total
+    ops.sum_parts(parts[:0], ss, accumulate=False)
+    assert float(ss) == 0.0
     with pytest.raises((ValueError, RuntimeError)):          # 16-byte column pieces do not exist for 33 columns
         ops.dw_group([(prob[0][0], prob[0][1], torch.zeros(33, 128, device=DEV), None, 33)])
 
