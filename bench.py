@@ -353,14 +353,14 @@ def train_throughput(dtype, dev, g=G, h=H, steps=20, warmup=5, dist=None, rank=0
     st = torch.from_numpy(O.synth_expression(8 * BATCH, g, 1 + rank) * 2 - 1).to(dev)
     graph = world == 1 and dist is None    # one hipGraph per iteration (parallel dW branches); DDP steps are eager
     for i in range(warmup):
-        eng.step(st[:BATCH], st[:BATCH], use_graph=graph)
+        eng.step(st[:BATCH], st[:BATCH], use_graph=graph, join=False)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(steps):
         lo = (i % 8) * BATCH
-        eng.step(st[lo:lo + BATCH], st[lo:lo + BATCH], use_graph=graph)
+        eng.step(st[lo:lo + BATCH], st[lo:lo + BATCH], use_graph=graph, join=False)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     eng.finish()

@@ -18,7 +18,7 @@ for i in range(n):
     eng.step(st[lo:lo + 512], st[lo:lo + 512], use_graph=True)
 torch.cuda.synchronize()
 full = (time.perf_counter() - t0) / n * 1e3
-gr = eng._graphs[512]["graph"]
+gr = eng._graphs[512][0]["graph"]
 with torch.cuda.stream(eng._stream):
     for i in range(3): gr.launch()
     torch.cuda.synchronize()

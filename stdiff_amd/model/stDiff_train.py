@@ -40,11 +40,13 @@ def normal_train_stDiff(model,
         for i, (x, x_cond) in enumerate(dataloader):
             x = x.float().to(dev, non_blocking=True).contiguous()
             x_cond = x_cond.float().to(dev, non_blocking=True).contiguous()
-            loss, _ = eng.step(x, x_cond, use_graph=use_graph)
-            epoch_loss += loss
+            # join=False: this stream does not wait for the iteration, so the next batch is uploaded and staged while it runs
+            loss, _ = eng.step(x, x_cond, use_graph=use_graph, join=False)
+            eng.accumulate(epoch_loss, loss)
             n = i + 1
         if epoch + 1 == num_epoch:
             eng.finish()                        # the last iteration's update
+        eng.sync()
         epoch_loss = float(epoch_loss) / max(n, 1)
         if is_tqdm:
             t_epoch.set_postfix_str(f'{pred_type} loss:{epoch_loss:.5f}')

@@ -676,7 +676,7 @@ class TrainEngine(TrainCore):
                     self.mirror.copy_(self.flat_p)
                 self.pw.refresh()
         self.buckets = self.bucket_ranges()
-        self._graphs, self._stream = {}, None
+        self._graphs, self._stream, self._stage_stream, self._flip = {}, None, None, 0
         self.fold_norm = os.environ.get("STDIFF_TRAIN_FOLD_NORM", "1") != "0"
         self.lazy = bool(lazy_update) and self.world == 1 and os.environ.get("STDIFF_TRAIN_LAZY", "1") != "0"
         self._pending, self._opt_stream = False, None
@@ -687,18 +687,24 @@ class TrainEngine(TrainCore):
         assert all(lo0 <= self.offs[n] < hi0 for n in self.pw.w if n not in self.mirrored), \
             "operands that need a repack after the optimizer must lie in the first update range"
 
-    def step(self, x, x_cond, noise=None, timesteps=None, use_graph=False):
+    def step(self, x, x_cond, noise=None, timesteps=None, use_graph=False, join=True):
         """x, x_cond: fp32 [C, G] on the device.  Returns (loss[1], grad_norm[1]) device tensors (no host sync).
 
         use_graph=True replays the whole iteration (≈340 launches: add-noise .. AdamW .. operand repack) as ONE
         hipGraph per batch size; inputs are staged into fixed buffers first.  Single process only: with a process
-        group the bucketed all-reduce is issued from the host between backward segments."""
+        group the bucketed all-reduce is issued from the host between backward segments.
+
+        join=False (graph replays only): the caller's stream is NOT made to wait for the iteration.  The inputs of the
+        next step() are then staged (two copies, the noise and timestep draws) on a stream of their own while this
+        iteration still runs, into the other of two staging sets, instead of between two replays on the replay stream
+        (48 us of a 2.38 ms iteration).  The returned tensors -- and every engine buffer -- are then current on
+        `self.stream` only: use accumulate() for running sums, and finish() / sync() before reading on another stream."""
         C = x.shape[0]
         dev = self.device
         self.pw.fused_stale = True       # the optimizer kernel rewrites the operand mirror without going through refresh()
         if use_graph and self.world == 1 and not (self.lazy and not self._pending):
             # (a lazy engine's first step has no pending update: enqueued eagerly, the graph is captured on the second)
-            return self._step_graph(x, x_cond, noise, timesteps)
+            return self._step_graph(x, x_cond, noise, timesteps, join)
         a = self.acts(C)
         if noise is None:
             noise = torch.randn(x.shape, device=dev)                                   # stDiff_train.py:62
@@ -740,6 +746,7 @@ class TrainEngine(TrainCore):
 
     def finish(self):
         """Applies the update a lazy step() left pending (no-op otherwise): call before reading parameters."""
+        self.sync()                                 # iterations issued with join=False
         if self._pending:
             ops.clip_adamw(self.flat_p, self.flat_g, self.m, self.v, self.sumsq, self.step_dev, self.scal, self.lr,
                            max_norm=self.max_norm, grad_scale=1.0 / self.world, betas=self.betas, eps=self.eps,
@@ -786,43 +793,98 @@ class TrainEngine(TrainCore):
                        weight_decay=self.wd, bf16_mirror=self.mirror)                  # :78-80
         self.refresh_weights()
 
-    def _step_graph(self, x, x_cond, noise, timesteps):
-        C, dev = x.shape[0], self.device
-        st = self._graphs.get(C)
-        if st is None:
+    @property
+    def stream(self):
+        """The stream the captured iterations replay on (None before the first replay)."""
+        return self._stream
+
+    def sync(self):
+        """Make the current stream wait for every iteration issued so far (needed after step(join=False))."""
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+
+    def accumulate(self, total, value):
+        """total += value on the stream the iterations run on (the epoch's loss sum with step(join=False))."""
+        if self._stream is None:
+            total += value
+            return
+        with torch.cuda.stream(self._stream):
+            total += value
+
+    def _staging(self, C, k):
+        sets = self._graphs.get(C)
+        if sets is None:
             if len(self._graphs) > 3:
                 self._graphs.clear()           # ops.Graph frees its exec handle when collected
-            st = self._graphs[C] = dict(
+            sets = self._graphs[C] = [None, None]
+        if sets[k] is None:
+            dev = self.device
+            sets[k] = dict(
                 x=torch.empty((C, self.G), device=dev), y=torch.empty((C, self.G), device=dev),
                 noise=torch.empty((C, self.G), device=dev), t=torch.empty((C,), device=dev, dtype=torch.int64),
-                graph=None)
+                graph=None, busy=None)
+        return sets[k]
+
+    def _stage(self, st, x, x_cond, noise, timesteps):
+        st["x"].copy_(x)
+        st["y"].copy_(x_cond)
+        if noise is None:
+            st["noise"].normal_()                                                  # stDiff_train.py:62
+        else:
+            st["noise"].copy_(noise)
+        if timesteps is None:
+            st["t"].random_(1, self.T)                                             # :63  (t = 0 never drawn)
+        else:
+            st["t"].copy_(timesteps)
+
+    def _replay(self, st, C):
+        if st["graph"] is None:
+            a = st["a"] = self.acts(C)          # the graph records these addresses: keep the set alive with it
+            g = ops.Graph()
+            g.begin()
+            try:
+                self._enqueue(a, st["x"], st["y"], st["noise"], st["t"])
+            finally:
+                g.end()
+            st["events"] = a.pop("_ready_events", None)        # (both staging sets share the activations)
+            st["graph"] = g
+        st["graph"].launch()
+
+    def _step_graph(self, x, x_cond, noise, timesteps, join=True):
+        C, dev = x.shape[0], self.device
         if self._stream is None:
             from .engine import lane_streams
             self._stream = lane_streams(dev, 1)[0]             # the legacy default stream cannot be captured
         cur = torch.cuda.current_stream()
-        self._stream.wait_stream(cur)
+        if join:
+            st = self._staging(C, 0)
+            self._stream.wait_stream(cur)
+            with torch.cuda.stream(self._stream):
+                self._stage(st, x, x_cond, noise, timesteps)
+                self._replay(st, C)
+                st["busy"] = None
+            cur.wait_stream(self._stream)
+            return self.loss, self.scal[3:4]
+        # pipelined: staging set k alternates; its previous reader is the replay of two steps ago
+        if self._stage_stream is None:
+            from .engine import aux_stream
+            self._stage_stream = aux_stream(dev, "stage")
+        k = self._flip = self._flip ^ 1
+        st = self._staging(C, k)
+        S = self._stage_stream
+        S.wait_stream(cur)                                     # the inputs are ready on the caller's stream
+        if st["busy"] is not None:
+            S.wait_event(st["busy"])
+        with torch.cuda.stream(S):
+            self._stage(st, x, x_cond, noise, timesteps)
+        for tns in (x, x_cond, noise, timesteps):              # the caller may drop them before S has read them
+            if tns is not None:
+                tns.record_stream(S)
+        self._stream.wait_stream(S)
         with torch.cuda.stream(self._stream):
-            st["x"].copy_(x)
-            st["y"].copy_(x_cond)
-            if noise is None:
-                st["noise"].normal_()                                                  # stDiff_train.py:62
-            else:
-                st["noise"].copy_(noise)
-            if timesteps is None:
-                st["t"].random_(1, self.T)                                             # :63  (t = 0 never drawn)
-            else:
-                st["t"].copy_(timesteps)
-            if st["graph"] is None:
-                a = st["a"] = self.acts(C)          # the graph records these addresses: keep the set alive with it
-                g = ops.Graph()
-                g.begin()
-                try:
-                    self._enqueue(a, st["x"], st["y"], st["noise"], st["t"])
-                finally:
-                    g.end()
-                st["graph"] = g
-            st["graph"].launch()
-        cur.wait_stream(self._stream)
+            self._replay(st, C)
+            st["busy"] = torch.cuda.Event()
+            st["busy"].record(self._stream)
         return self.loss, self.scal[3:4]
 
 

@@ -254,7 +254,7 @@ def test_train_odd_gene_counts_against_oracle(G, use_graph):
         for n in ("in_layer.0.weight", "cond_layer.0.weight", "out_layer.linear.weight", "out_layer.linear.bias"):
             assert float((te.g[n].cpu() - raw[n]).abs().max()) < 1e-4 * gscale, (lo, n)
     if use_graph:
-        assert len(te._graphs) == 2 and all("a" in st_ for st_ in te._graphs.values())
+        assert len(te._graphs) == 2 and all("a" in sets[0] for sets in te._graphs.values())   # one graph per batch size
 
 
 def test_autograd_bridge_matches_oracle():
@@ -850,3 +850,42 @@ def test_training_iterations_repeat_bit_for_bit(dtype):
     assert a[3] == b[3] and all(n > 0 for n in a[3])
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     assert all(abs(p - q) < 1e-5 * abs(q) for p, q in zip(a[4], b[4]))
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp32"])
+def test_unjoined_steps_equal_joined_steps(dtype):
+    """step(join=False): the caller's stream does not wait for the iteration; the next step's inputs are staged on a
+    stream of their own, into the other of two staging sets (two captured graphs), while the iteration runs.  Same
+    kernels on the same data in the same order: parameters, moments and gradient norms equal the joined engine's bit for
+    bit, the loss sum kept with accumulate() equals the sum of the joined losses; inputs are dropped right after each
+    call (record_stream keeps them alive for the staging stream)."""
+    from stdiff_amd.train_engine import TrainEngine
+    G, H, depth, heads, T, C = 72, 128, 3, 4, 1000, 96
+    mask = O.kfold_mask(G, 1)
+    base = torch.from_numpy((O.synth_expression(C, G, 9) * 2 - 1).astype(np.float32)).to(DEV)
+    mk = torch.from_numpy(mask).to(DEV)
+    res = {}
+    for join in (True, False):
+        m, _ = build(G, H, depth, heads, 71, dtype)
+        te = TrainEngine(m, lr=1e-3, diffusion_step=T, mask=mask, lazy_update=True)
+        gen = torch.Generator().manual_seed(5)
+        total = torch.zeros(1, device=DEV)
+        norms = []
+        for i in range(7):
+            x = base * (1.0 + 0.01 * i)                       # a fresh tensor per step, dropped after the call
+            xc = (x * mk).float()
+            noise = torch.randn(C, G, generator=gen).to(DEV)
+            tt = torch.randint(1, T, (C,), generator=gen).to(DEV)
+            loss, _ = te.step(x, xc, noise=noise, timesteps=tt, use_graph=True, join=join)
+            te.accumulate(total, loss)
+            del x, xc, noise, tt
+            if join:
+                norms.append(float(te.sumsq))
+        te.finish()
+        assert not te._pending
+        res[join] = (te.flat_p.clone(), te.m.clone(), te.v.clone(), float(total), float(te.scal[3]))
+        if not join:
+            assert all(s is not None and s["graph"] is not None for s in te._graphs[C])      # both sets were used
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert a[4] == b[4] and abs(a[3] - b[3]) < 1e-5 * abs(a[3])
