@@ -325,15 +325,19 @@ int backward_grouped(Ctx& c, stdiff_bucket_fn after_bucket, void* user) {
         TRY(c.group(g, [&](bool sd) {
             TRY(c.norm(sd, D - k));
             TRY(c.sum_parts(sd));
-            return c.dX(sd, C, dmod, 6 * H, 6 * H, b.ada, 6 * H, H, a->ds32, H, STDIFF_F32, STDIFF_EPI_ACCUM);
+            TRY(c.dX(sd, C, dmod, 6 * H, 6 * H, b.ada, 6 * H, H, a->ds32, H, STDIFF_F32, STDIFF_EPI_ACCUM));
+            // block 0: d loss / d h0 is final since the LayerNorm-1 backward above; its operand copy (in_layer's weight
+            // gradient reads it) is made here, beside the chain
+            if (k == 0) TRY(stdiff_pack_rows(a->dh, H, a->dhT, H, dt, C, H, H, c.st(sd)));
+            return (int)STDIFF_OK;
         }));
     }
     TRY(c.join());                                 // the last group: ds32 is complete
     if (after_bucket) after_bucket(D, user);
     // ---- embeddings: h0 = in_layer(x); c = time_emb(t) + cond_layer(y); s = silu(c)   (:231-239)
-    TRY(stdiff_pack_rows(a->dh, H, a->dhT, H, dt, C, H, H, stream));
-    TRY(stdiff_silu_bwd(a->ds32, H, STDIFF_F32, a->c, H, STDIFF_F32, a->dc, H, STDIFF_F32, 0, C, H, stream));
-    TRY(stdiff_pack_rows(a->dc, H, a->dcT, H, dt, C, H, H, stream));
+    if (D == 0) TRY(stdiff_pack_rows(a->dh, H, a->dhT, H, dt, C, H, H, stream));
+    // d loss / d c straight into the operand format (the fp32 copy a->dc had no other reader: one launch less)
+    TRY(stdiff_silu_bwd(a->ds32, H, STDIFF_F32, a->c, H, STDIFF_F32, a->dcT, H, dt, 0, C, H, stream));
     TRY(c.dX(false, C, a->dcT, H, H, w->t2, H, H, a->de1, H, dt));
     TRY(stdiff_silu_bwd(a->de1, H, dt, a->a1, H, dt, a->da1, H, dt, 0, C, H, stream));
     {

@@ -496,14 +496,16 @@ class TrainCore:
                          (p + "attn.proj", dbra[q], a["o"][k])],
                         then=lambda sd, p=p, dmod=dmod, k=k: (norm(D - k),
                                                               self._dX(p + "adaLN_modulation.1", dmod, a["ds32"],
-                                                                       epi=L.EPI_ACCUM, side=sd)),
+                                                                       epi=L.EPI_ACCUM, side=sd),
+                                                              # d loss / d h0 is final: its operand copy, beside the chain
+                                                              k == 0 and ops.pack_rows(a["dh"], H, self.tdt, out=a["dhT_"])),
                         parts=gsq)
         self._side_join()
         if after_bucket:
             after_bucket(D)
-        ops.pack_rows(a["dh"], H, self.tdt, out=a["dhT_"])
-        ops.silu_bwd(a["ds32"], a["c"], a["dc"])
-        ops.pack_rows(a["dc"], H, self.tdt, out=a["dcT_"])
+        if D == 0:
+            ops.pack_rows(a["dh"], H, self.tdt, out=a["dhT_"])
+        ops.silu_bwd(a["ds32"], a["c"], a["dcT_"])        # straight into the operand format (no fp32 copy, no pack)
         self._dX("time_emb.mlp.2", a["dcT_"], a["de1"])
         ops.silu_bwd(a["de1"], a["a1"], a["da1"])
         self._side_on = False
