@@ -459,11 +459,14 @@ typedef struct {
     /* != 0: never leave a GEMM result as split-K partial products for its consumer (stdiff_gemm_args.defer): every split
      * GEMM is followed by its reduce launch, as before ABI 11 (A/B timing; results are bit-identical either way) */
     int no_defer;
-    /* Optional host array of depth + 2 hipEvent_t (NULL: none): stdiff_dit_train_forward makes its streams wait for
-     * param_ready[0] before the first use of the embedding layers' parameters (time MLP, cond, in), for
-     * param_ready[1 + k] before block k's, and for param_ready[depth + 1] before the final layer's -- the events an
+    /* Optional host array of 4 * depth + 2 hipEvent_t (NULL: none; NULL entries are skipped): stdiff_dit_train_forward
+     * makes its streams wait for param_ready[0] before the first use of the embedding layers' parameters (time MLP, cond,
+     * in); for block k for param_ready[1 + 4k] before its adaLN projection (and with it before the block), and -- for a
+     * block whose parameters are updated in pieces, else NULL -- for [2 + 4k] before qkv (proj is in the same piece),
+     * [3 + 4k] before fc1, [4 + 4k] before fc2; and for param_ready[4 * depth + 1] before the final layer's: the events an
      * optimizer records after updating those ranges on another stream (stdiff_adamw_range), so that the update of
-     * iteration i - 1 runs under the forward of iteration i.  Already-recorded events only. */
+     * iteration i - 1 runs under the forward of iteration i.  Already-recorded events only.  Every wait is a
+     * cross-stream edge that costs several microseconds: pieces pay only where the update, not the forward, sets the pace. */
     void* const* param_ready;
     /* Optional (NULL: none; honoured by the grouped backward only): the squared gradient norm accumulated range by range
      * as the backward finishes each gradient bucket -- *sumsq += sum g^2 over [lo[i], lo[i] + count[i]) for bucket i of

@@ -396,7 +396,7 @@ extern "C" int stdiff_dit_train_forward(const stdiff_train_weights* w, const std
         TRYH(hipEventRecord(c.ev[0], c.main));
         TRYH(hipStreamWaitEvent(c.side, c.ev[0], 0));
         for (int k = 0; k <= D; ++k) {
-            TRY(ready(c.side, 1 + k));
+            TRY(ready(c.side, 1 + 4 * k));             // k == D: the final layer's slot
             if (k < D) TRY(c.lin(true, C, 6 * H, H, a->s, H, w->blocks[k].ada, H, a->blocks[k].mod, 6 * H, dt));
             else TRY(c.lin(true, C, 2 * H, H, a->s, H, w->fada, H, a->fmod, 2 * H, dt));
             TRYH(hipEventRecord(c.ev[3 + k], c.side));
@@ -421,10 +421,11 @@ extern "C" int stdiff_dit_train_forward(const stdiff_train_weights* w, const std
         if (fork) {
             TRYH(hipStreamWaitEvent(c.main, c.ev[3 + k], 0));
         } else {
-            TRY(ready(c.main, 1 + k));
+            TRY(ready(c.main, 1 + 4 * k));
             TRY(c.lin(false, C, 6 * H, H, a->s, H, b.ada, H, s.mod, 6 * H, dt));
         }
         TRY(c.ln(pend, s.h, H, col(s.mod, dt, 0), col(s.mod, dt, H), 6 * H, s.xn1, s.mean1, s.rstd1));
+        TRY(ready(c.main, 1 + 4 * k + 1));              // (NULL unless the block is updated in pieces)
         TRY(c.lin(false, C, 3 * H, H, s.xn1, H, b.qkv, H, s.qkv, 3 * H, dt));
         TRY(stdiff_attention_fwd(s.qkv, 3 * H, s.o, H, s.lse, a->cu_rows, 1, C, w->heads, d, dt, stream));
         Ctx::Pend mid;
@@ -433,8 +434,10 @@ extern "C" int stdiff_dit_train_forward(const stdiff_train_weights* w, const std
         TRY(c.lin(false, C, H, H, s.o, H, b.proj, H, s.hmid, H, STDIFF_F32, STDIFF_EPI_GATE_RES, col(s.mod, dt, 2 * H),
                   6 * H, s.h, H, s.pa, H, &mid.sp));
         TRY(c.ln(mid, s.hmid, H, col(s.mod, dt, 3 * H), col(s.mod, dt, 4 * H), 6 * H, s.xn2, s.mean2, s.rstd2));
+        TRY(ready(c.main, 1 + 4 * k + 2));
         TRY(c.lin(false, C, 4 * H, H, s.xn2, H, b.fc1, H, s.u, 4 * H, dt, STDIFF_EPI_GELU_SAVE, nullptr, 0, nullptr, 0,
                   s.upre, 4 * H));
+        TRY(ready(c.main, 1 + 4 * k + 3));
         pend = Ctx::Pend();
         pend.bias = b.fc2.b; pend.gate = col(s.mod, dt, 5 * H); pend.ldgate = 6 * H; pend.res = s.hmid; pend.ldres = H;
         pend.v = s.pm; pend.ldv = H;
@@ -444,7 +447,7 @@ extern "C" int stdiff_dit_train_forward(const stdiff_train_weights* w, const std
     if (fork) {
         TRYH(hipStreamWaitEvent(c.main, c.ev[3 + D], 0));
     } else {
-        TRY(ready(c.main, 1 + D));
+        TRY(ready(c.main, 1 + 4 * D));
         TRY(c.lin(false, C, 2 * H, H, a->s, H, w->fada, H, a->fmod, 2 * H, dt));
     }
     TRY(c.ln(pend, a->h_last, H, col(a->fmod, dt, 0), col(a->fmod, dt, H), 2 * H, a->xnf, a->meanf, a->rstdf));

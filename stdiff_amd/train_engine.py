@@ -251,13 +251,14 @@ class TrainCore:
     # ------------------------------------------------------------------ forward (stDiff_model.py:231-243)
     def forward(self, a, t, param_ready=None):
         """a['xp'], a['yp'] hold the packed inputs; returns eps fp32 [C, G] (a['eps']).
-        param_ready: depth + 2 recorded torch.cuda.Event (embedding layers, block 0 .., final layer): the forward waits
-        for each where that range of parameters is first used (an optimizer updating them on another stream)."""
+        param_ready: 4 * depth + 2 slots of recorded torch.cuda.Event or None (stdiff_train_acts.param_ready: embedding
+        layers; per block adaLN projection / qkv + proj / fc1 / fc2; final layer): the forward waits for each where those
+        parameters are first used (an optimizer updating them on another stream)."""
         if self.c_enqueue:
             side = self._c_side()
             ca = self._c_acts(a)
             if param_ready is not None:
-                arr = (L.vp * len(param_ready))(*[e.cuda_event for e in param_ready])
+                arr = (L.vp * len(param_ready))(*[e.cuda_event if e is not None else None for e in param_ready])
                 ca.param_ready = L.C.cast(arr, L.C.POINTER(L.vp))
             try:
                 L.check(L.lib().stdiff_dit_train_forward(self._c_weights(), ca, L.ptr(t), side, L.stream()))
@@ -268,7 +269,7 @@ class TrainCore:
         g = self._gemm
 
         def params_ready(i, st=None):
-            if param_ready is not None:
+            if param_ready is not None and param_ready[i] is not None:
                 (st or torch.cuda.current_stream()).wait_event(param_ready[i])
         ops.timestep_embedding(t, self.pw.freqs, out=a["e0"])
         params_ready(0)
@@ -292,7 +293,7 @@ class TrainCore:
             with torch.cuda.stream(self._side):
                 for k in range(D + 1):
                     name = f"blks.{k}.adaLN_modulation.1" if k < D else "out_layer.adaLN_modulation.1"
-                    params_ready(1 + k, self._side)
+                    params_ready(1 + 4 * k, self._side)
                     w, b = self._lin(name)
                     g(a["s"], w, b, out=a["mod"][k] if k < D else a["fmod"], side=True)
                     ev = torch.cuda.Event()
@@ -309,14 +310,15 @@ class TrainCore:
         for k in range(D):
             p = f"blks.{k}."
             mod = a["mod"][k]
-            if mod_ready is None:             # (else mod_ready[k] already orders this stream behind param_ready[1 + k])
-                params_ready(1 + k)
+            if mod_ready is None:             # (else mod_ready[k] already orders this stream behind param_ready[1 + 4k])
+                params_ready(1 + 4 * k)
                 w, b = self._lin(p + "adaLN_modulation.1")
                 g(a["s"], w, b, out=mod)
             else:
                 torch.cuda.current_stream().wait_event(mod_ready[k])
             ops.ln_modulate(a["h"][k], mod[:, 0:H], mod[:, H:2 * H], out=a["xn1"][k], mean=a["mean1"][k], rstd=a["rstd1"][k],
                             **pend)
+            params_ready(2 + 4 * k)           # (None unless the block is updated in pieces)
             w, b = self._lin(p + "attn.qkv")
             g(a["xn1"][k], w, b, out=a["qkv"][k])
             ops.attention_fwd(a["qkv"][k], a["cu"], a["C"], self.heads, out=a["o"][k], lse=a["lse"][k])
@@ -326,14 +328,16 @@ class TrainCore:
               defer=mid["split"])
             ops.ln_modulate(a["hmid"][k], mod[:, 3 * H:4 * H], mod[:, 4 * H:5 * H], out=a["xn2"][k], mean=a["mean2"][k],
                             rstd=a["rstd2"][k], **mid)
+            params_ready(3 + 4 * k)
             w, b = self._lin(p + "mlp.fc1")
             g(a["xn2"][k], w, b, out=a["u"][k], epi=L.EPI_GELU_SAVE, out2=a["upre"][k])
+            params_ready(4 + 4 * k)
             w, b = self._lin(p + "mlp.fc2")
             pend = dict(split=sr(mod_ready is not None), bias=b, gate=mod[:, 5 * H:6 * H], res=a["hmid"][k], v_out=a["pm"][k])
             g(a["u"][k], w, b, out=a["h"][k + 1], epi=L.EPI_GATE_RES, gate=mod[:, 5 * H:6 * H], res=a["hmid"][k], out2=a["pm"][k],
               defer=pend["split"])
         if mod_ready is None:
-            params_ready(1 + D)
+            params_ready(1 + 4 * D)
             w, b = self._lin("out_layer.adaLN_modulation.1")
             g(a["s"], w, b, out=a["fmod"])
         else:
@@ -684,7 +688,30 @@ class TrainEngine(TrainCore):
         self._pending, self._opt_stream = False, None
         # update ranges in the order the forward first touches them: embedding layers, block 0 .. depth-1, final layer
         # (the all-reduce buckets in reverse)
-        self.update_ranges = [self.buckets[-1]] + self.buckets[-2:0:-1] + [self.buckets[0]]
+        per_block = [self.buckets[-1]] + self.buckets[-2:0:-1] + [self.buckets[0]]
+        # The LAST blocks' ranges may be cut into four pieces in the order the forward uses them (adaLN projection -- last
+        # in the flat buffer, first to be used --, qkv + proj, fc1, fc2), each with its own event: where the update sets
+        # the pace (hidden 2048: 487 us per block range against 170 us of forward per block) the forward's tail behind the
+        # last range shrinks from a whole block to one GEMM.  Every piece costs a launch and a cross-stream edge: measured
+        # on the 512-cell iteration, pieces for the last 0 / 1 / 2 / 3 / 6 blocks give 6.04 / 6.01 / 6.00 / 6.13 / 6.48 ms at
+        # hidden 2048 and 2.36 / 2.37 / 2.38 ms at hidden 1024 (where the forward, not the update, sets the pace) -- so the
+        # last two blocks of wide models only (STDIFF_TRAIN_UPDATE_PIECES = number of blocks, 0 = none).
+        e = os.environ.get("STDIFF_TRAIN_UPDATE_PIECES", "")
+        self.piece_blocks = min(self.depth, int(e) if e else (2 if self.H >= 1536 else 0))
+        self.update_ranges, self.update_slots = [per_block[0]], [0]        # (range, param_ready slot)
+        for k in range(self.depth):
+            lo, hi = per_block[1 + k]
+            if k >= self.depth - self.piece_blocks:
+                o = lambda n, k=k: self.offs[f"blks.{k}.{n}.weight"]
+                assert lo == o("attn.qkv") < o("mlp.fc1") < o("mlp.fc2") < o("adaLN_modulation.1") < hi
+                self.update_ranges += [(o("adaLN_modulation.1"), hi), (lo, o("mlp.fc1")), (o("mlp.fc1"), o("mlp.fc2")),
+                                       (o("mlp.fc2"), o("adaLN_modulation.1"))]
+                self.update_slots += [1 + 4 * k, 2 + 4 * k, 3 + 4 * k, 4 + 4 * k]
+            else:
+                self.update_ranges.append((lo, hi))
+                self.update_slots.append(1 + 4 * k)
+        self.update_ranges.append(per_block[-1])
+        self.update_slots.append(1 + 4 * self.depth)
         lo0, hi0 = self.update_ranges[0]
         assert all(lo0 <= self.offs[n] < hi0 for n in self.pw.w if n not in self.mirrored), \
             "operands that need a repack after the optimizer must lie in the first update range"
@@ -744,7 +771,11 @@ class TrainEngine(TrainCore):
                 ev.record(self._opt_stream)
                 events.append(ev)
         self._fork_event = events.pop(0)
-        return events
+        self._last_update_event = events[-1]
+        ready = [None] * (4 * self.depth + 2)              # stdiff_train_acts.param_ready: one slot per use point
+        for slot, ev in zip(self.update_slots, events):
+            ready[slot] = ev
+        return ready
 
     def finish(self):
         """Applies the update a lazy step() left pending (no-op otherwise): call before reading parameters."""
@@ -763,7 +794,7 @@ class TrainEngine(TrainCore):
         eps = self.forward(a, timesteps, param_ready=ready)                            # :72
         if ready is not None:
             a["_ready_events"] = (self._fork_event, ready)      # a captured graph keeps its events alive
-            torch.cuda.current_stream().wait_event(ready[-1])      # the update has read every gradient
+            torch.cuda.current_stream().wait_event(self._last_update_event)      # the update has read every gradient
         hooked = self.world > 1 or (self.force_buckets and self.dist is not None)
         # single process + grouped backward: the gradient norm is accumulated inside the backward
         fold_norm = self.fold_norm and not hooked and "dbr_b" in a

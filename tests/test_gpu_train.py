@@ -889,3 +889,36 @@ def test_unjoined_steps_equal_joined_steps(dtype):
     a, b = res[True], res[False]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     assert a[4] == b[4] and abs(a[3] - b[3]) < 1e-5 * abs(a[3])
+
+
+@pytest.mark.parametrize("dtype,enqueue", [("bf16", "c"), ("fp32", "c"), ("bf16", "py")])
+def test_update_in_pieces_equals_whole_block_ranges(dtype, enqueue, monkeypatch):
+    """The lazy update with the last blocks' ranges cut into four pieces in the order the forward uses them (adaLN
+    projection, qkv + proj, fc1, fc2; one param_ready slot each, the default for wide models) against whole-block
+    ranges: every element goes through the same arithmetic once, so parameters and moments are equal bit for bit, and
+    the pieces tile each block's range exactly."""
+    from stdiff_amd.train_engine import TrainEngine
+    monkeypatch.setenv("STDIFF_TRAIN_ENQUEUE", enqueue)
+    G, H, depth, heads, T, C = 72, 128, 3, 4, 1000, 96
+    mask = O.kfold_mask(G, 1)
+    x = torch.from_numpy((O.synth_expression(C, G, 9) * 2 - 1).astype(np.float32)).to(DEV)
+    xc = (x * torch.from_numpy(mask).to(DEV)).float()
+    res = {}
+    for pieces in ("0", "2", "3"):
+        monkeypatch.setenv("STDIFF_TRAIN_UPDATE_PIECES", pieces)
+        m, _ = build(G, H, depth, heads, 71, dtype)
+        te = TrainEngine(m, lr=1e-3, diffusion_step=T, mask=mask, lazy_update=True)
+        assert te.piece_blocks == int(pieces) and len(te.update_ranges) == depth + 2 + 3 * int(pieces)
+        covered = sorted(te.update_ranges)
+        assert covered[0][0] == 0 and covered[-1][1] == te.total
+        assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))          # the ranges tile the flat buffer
+        gen = torch.Generator().manual_seed(5)
+        for i in range(5):
+            noise = torch.randn(C, G, generator=gen).to(DEV)
+            tt = torch.randint(1, T, (C,), generator=gen).to(DEV)
+            te.step(x, xc, noise=noise, timesteps=tt, use_graph=(enqueue == "c"))
+        te.finish()
+        res[pieces] = (te.flat_p.clone(), te.m.clone(), te.v.clone())
+    for pieces in ("2", "3"):
+        for a_, b_ in zip(res["0"], res[pieces]):
+            assert torch.equal(a_, b_), pieces
