@@ -16,7 +16,10 @@
 //                    optional K-major operands (transposed LDS reads) and deterministic split-K through a caller
 //                    workspace.  bf16: v_mfma_f32_16x16x32_bf16;  f32: v_mfma_f32_16x16x4_f32 (a k-ordered fp32
 //                    fmaf chain).
-// Both send the accumulators through an fp32 LDS image of the C tile so that the epilogue (bias / SiLU / GELU-erf /
+//   gemm128d_kernel  the same 128 x 128 tile for 16-bit row-major operands on grids of at most one workgroup per CU (the
+//                    batch-sized forward GEMMs of a training step): LDS-DMA staging into a ring of four slab buffers,
+//                    eight waves, one barrier per slab; the same bits as gemm_nt_kernel.
+// All of them send the accumulators through an fp32 LDS image of the C tile so that the epilogue (bias / SiLU / GELU-erf /
 // gate*v+res / +res / accumulate / save-pre-activation) loads and stores whole row pieces, in batches whose latencies
 // overlap.  The epilogue math is a compile-time template parameter dispatched ONCE per block: a runtime switch inside
 // the unrolled store loop replicated the erf/exp code 32x (128 KiB of instructions) and cost 13 us per tile.
@@ -1454,6 +1457,179 @@ __global__ __launch_bounds__(512, 1) void gemm256q_kernel(Params p) {
     }
 }
 
+// ================================================================ 16-bit, 128 x 128 tile, LDS-DMA staging (batch-sized GEMMs)
+// gemm_nt_kernel stages its operands through registers (global -> VGPR -> ds_write): on a grid of one workgroup per CU
+// that path is what bounds the K loop (0.69 us per 64-wide slab against 0.21 us of MFMA: profiles/notes/
+// r03_training_step.md).  This variant of the same tile -- same fragment reads, same MFMA order, the same bits -- fills
+// a ring of four slab buffers by LDS-DMA instead (global_load_lds, 16 B per lane, no VGPR round trip, no ds_write),
+// three slabs ahead, with ONE barrier per slab and counted waits.  The LDS image is lane-linear, so the XOR swizzles of
+// the register-staged kernel are applied to the per-lane SOURCE address.  Row-major A; W row-major or K-major (WK: the
+// input-gradient GEMMs); rows / columns past the edges and K-major rows k >= k_valid read as zeros through the buffer
+// descriptor's range check (columns past N of a K-major W: an offset forced out of range).  One workgroup per CU
+// (128 KiB of LDS): selected for the grids gemm_nt_kernel runs with three slabs of loads in flight.
+// NW = 8: eight waves (2 x 4, a wave owns 64 x 32 outputs) instead of four (2 x 2, 64 x 64): two waves per SIMD, so one
+// wave's fragment reads run under the other's MFMAs (with one wave per SIMD they alternate: 0.25 us of LDS reads +
+// 0.25 us of MFMA per slab).  Every output element still sums its products in the same order: same bits.
+template <bool WK, int NW>
+__global__ __launch_bounds__(512, 1) void gemm128d_kernel(Params p) {
+    using T = bf16_t;
+    constexpr int TILEB = 16384, STAGES = 4;       // one operand tile: 128 rows x 128 B, or 64 k-rows x 256 B
+    constexpr int NTW = NW == 8 ? 2 : 4;           // 16-column fragments per wave; DMA instructions per wave and operand: 16 / NW
+    constexpr int DPW = 16 / NW;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * 2 * TILEB];
+    static_assert(STAGES * 2 * TILEB >= BM * CLD * 4, "the fp32 C image reuses the ring");
+
+    int tm, tn;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int split = bid / ntiles;
+    tile_of(bid - split * ntiles, ntiles, p.tiles_m, p.tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = NW == 8 ? wid >> 2 : wid >> 1, wn = NW == 8 ? wid & 3 : wid & 1;
+    const int wcol = wn * (NW == 8 ? 32 : 64);
+    const int fr = lane & 15, fq = lane >> 4;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.A), 0, (int)(((unsigned)(p.M - 1) * p.lda + p.K) * 2u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.W), 0,
+        WK ? (int)(((unsigned)(p.k_valid - 1) * p.ldw + p.N) * 2u) : (int)(((unsigned)(p.N - 1) * p.ldw + p.K) * 2u), 0x00020000);
+    // per-lane source offsets (bytes) of this wave's DMA instructions per operand and slab; instruction j fills bytes
+    // [(DPW wid + j) KiB, + 1 KiB) of the tile image
+    unsigned voffA[4], voffW[4];           // (DPW of them used)
+#pragma unroll
+    for (int j = 0; j < DPW; ++j) {
+        const int row = 8 * (DPW * wid + j) + (lane >> 3), slot = (lane & 7) ^ (lane >> 3);      // row & 7 == lane >> 3
+        voffA[j] = ((unsigned)(m0 + row) * (unsigned)p.lda + slot * 8) * 2u;
+        if constexpr (WK) {
+            const int k = 4 * (DPW * wid + j) + (lane >> 4), pp = lane & 15;
+            const int fk = (k & 3) | (((k >> 3) & 1) << 2);
+            const int piece = ((((pp >> 1) ^ fk)) << 1) | (pp & 1);
+            const int n = n0 + piece * 8;
+            voffW[j] = n < p.N ? ((unsigned)k * (unsigned)p.ldw + n) * 2u : 0x80000000u;
+        } else {
+            voffW[j] = ((unsigned)(n0 + row) * (unsigned)p.ldw + slot * 8) * 2u;
+        }
+    }
+    const int kb = split * p.nk_per, nk = min(p.K / 64 - kb, p.nk_per);     // this block's K-slabs
+    auto dma = [&](int slab, int stage) {
+        unsigned char* da = smem + stage * 2 * TILEB + (DPW * wid) * 1024;
+        unsigned char* dw = da + TILEB;
+        const unsigned ka = (unsigned)(kb + slab) * 128u;                                  // 64 k x 2 B along a row
+        const unsigned kw = WK ? (unsigned)(kb + slab) * 64u * (unsigned)p.ldw * 2u : ka;  // 64 k-rows
+#pragma unroll
+        for (int j = 0; j < DPW; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(da + j * 1024), 16,
+                                                     voffA[j] + ka, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(dw + j * 1024), 16,
+                                                     (WK && voffW[j] == 0x80000000u) ? 0x80000000u : voffW[j] + kw, 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];              // (NW = 8 uses acc[.][0..1])
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragments exactly as gemm_nt_body reads them (row-major: 16-byte reads; K-major: transposed 4 x 16 block reads)
+    auto frags = [&](int stage, int ks, bf16x8 (&af)[4], bf16x8 (&wf)[4]) {
+        const unsigned char* ba = smem + stage * 2 * TILEB;
+        const unsigned char* bw = ba + TILEB;
+        const int slot = ks * 4 + fq;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ra_ = wm * 64 + t * 16 + fr;
+            af[t] = *(const bf16x8*)(ba + ra_ * 128 + ((slot ^ (ra_ & 7)) << 4));
+        }
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int rw_ = wcol + t * 16 + fr;
+            if constexpr (WK) {
+                const int kk = ks * 32 + 8 * fq + (fr >> 2), fk = (kk & 3) | (((kk >> 3) & 1) << 2);
+                const unsigned char* w0 = bw + kk * 256 + ((((wcol + t * 16) >> 4) ^ fk) << 5) + 8 * (fr & 3);
+                bf16x4 lo = ds_read_tr16_b64(w0);
+                bf16x4 hi = ds_read_tr16_b64(w0 + 4 * 256);
+                wf[t] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            } else {
+                wf[t] = *(const bf16x8*)(bw + rw_ * 128 + ((slot ^ (rw_ & 7)) << 4));
+            }
+        }
+    };
+    auto mma = [&](const bf16x8 (&af)[4], const bf16x8 (&wf)[4]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+                acc[mt][nt] = STDIFF_MFMA_16x16x32_H16(wf[nt], af[mt], acc[mt][nt], 0, 0, 0);
+    };
+
+    // Ring of four: slabs k + 1, k + 2 (and k + 3, issued behind the barrier) are in flight while slab k is multiplied; ONE
+    // barrier per slab.  (Pipelining the fragment reads across a barrier in the middle of the slab, as gemm_nt_body's
+    // deep variant does, was tried here and lost: 15.9 against 13.7 us for a K = 1024 launch.)
+#pragma unroll
+    for (int d = 0; d < STAGES - 1; ++d)
+        if (d < nk) dma(d, d);
+#pragma unroll 1
+    for (int k = 0; k < nk; ++k) {
+        const int rem = min(STAGES - 2, nk - 1 - k);       // slabs issued after slab k that may still be in flight
+        if constexpr (NW == 8) {
+            if (rem >= 2) STDIFF_VMCNT(8);
+            else if (rem == 1) STDIFF_VMCNT(4);
+            else STDIFF_VMCNT(0);
+        } else {
+            if (rem >= 2) STDIFF_VMCNT(16);
+            else if (rem == 1) STDIFF_VMCNT(8);
+            else STDIFF_VMCNT(0);
+        }
+        STDIFF_BARRIER();                                  // slab k is complete; every wave is done with slab k - 1
+        if (k + STAGES - 1 < nk) dma(k + STAGES - 1, (k + STAGES - 1) & (STAGES - 1));
+        const int stage = k & (STAGES - 1);
+        bf16x8 af0[4], wf0[4], af1[4], wf1[4];
+        frags(stage, 0, af0, wf0);
+        frags(stage, 1, af1, wf1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(af0, wf0);
+        mma(af1, wf1);
+    }
+    STDIFF_BARRIER();                                      // the last slab has been read: the C image may overwrite the ring
+
+    // ---- accumulators -> fp32 C image in LDS and out, as in gemm_nt_body (the first 256 threads run its epilogue)
+    float* cl = (float*)smem;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int m = wm * 64 + mt * 16 + fr, n = wcol + nt * 16 + fq * 4;
+            *(f32x4*)(cl + m * CLD + n) = acc[mt][nt];
+        }
+    __syncthreads();
+    if (NW == 8 && tid >= NT) return;
+    if (p.ksplit > 1) {                 // partial product -> workspace slice (splitk_reduce_kernel or a *_split consumer)
+        float* w = p.ws + (size_t)split * p.M * p.ldws;
+#pragma unroll 1
+        for (int i = 0; i < 16; ++i) {
+            const int r = (tid >> 5) + 8 * i, c4 = (tid & 31) * 4;
+            const int gm = m0 + r, gn = n0 + c4;
+            if (gm < p.M && gn < p.ldws) *(f32x4*)(w + (size_t)gm * p.ldws + gn) = *(const f32x4*)(cl + r * CLD + c4);
+        }
+        return;
+    }
+    if (p.vec) {
+#define STDIFF_CALL128D(E) epi_rows128<E, T>(p, cl, tid, m0, n0)
+        STDIFF_EPI_DISPATCH(STDIFF_CALL128D)
+        return;
+    }
+#pragma unroll 1
+    for (int i = 0; i < 16; ++i) {
+        const int r = (tid >> 4) + 16 * (i >> 1), c4 = (tid & 15) * 8 + 4 * (i & 1);
+        const int gm = m0 + r, gn = n0 + c4;
+        if (gm < p.M && gn < p.N) epilogue4_slow<T>(p, gm, gn, *(const f32x4*)(cl + r * CLD + c4));
+    }
+}
+
 // ================================================================ 16-bit, 192 x 256 tile, TWO tiles in flight per CU
 // gemm256q spends 17-29 % of a tile in its epilogue (LDS round trips, barriers, store issue) with the matrix cores idle,
 // and cannot overlap it with the next tile: one 256 x 256 fp32 tile is 128 of a wave's 256 registers.  This kernel makes
@@ -1806,7 +1982,7 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
 // one process).  Readers never see a half-written record: the pointer is swapped atomically and old records are left
 // alive (a few dozen bytes each).
 struct GemmEnv {
-    int tile, cus, split_tail, splitk_max, splitk_blocks, splitk_min, depth;
+    int tile, cus, split_tail, splitk_max, splitk_blocks, splitk_min, depth, dma128;
 };
 const GemmEnv* read_gemm_env() {
     auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e && *e ? atoi(e) : dflt; };
@@ -1817,6 +1993,10 @@ const GemmEnv* read_gemm_env() {
     e->splitk_max = num("STDIFF_SPLITK_MAX", 0);
     e->splitk_blocks = num("STDIFF_SPLITK_BLOCKS", 0);
     e->splitk_min = num("STDIFF_SPLITK_MIN", 0);
+    // the LDS-DMA variant of the 128 x 128 kernel: 1 (default) for row-major W -- the forward GEMMs of a training step,
+    // 16.4 -> 12.5 us per K = 1024 launch --, 2 also for K-major W (input gradients: faster alone, slower in the training
+    // step, where its 128 KiB of LDS keep the weight-gradient group off the CU: 6.15 against 5.95 ms), 0 off
+    e->dma128 = num("STDIFF_GEMM_DMA128", 1);
     e->depth = num("STDIFF_GEMM_DEPTH", 0);      // 1 / 3: force the 128 x 128 kernel's prefetch depth (A/B timing, tests)
     return e;
 }
@@ -2026,7 +2206,21 @@ int gemm_impl(const stdiff_gemm_args* a, void* stream, void* workspace, long lon
         if (deep) STDIFF_LAUNCH128_D(T, 3);                                                                    \
         else STDIFF_LAUNCH128_D(T, 1);                                                                         \
     } while (0)
-    if (!bf)
+    // 32-bit buffer offsets: both operands below 2 GiB
+    const bool dma128 = bf && tile == 1 && !ak && deep && env.dma128 != 0 && (!wk || env.dma128 == 2) &&
+                        ((unsigned long long)(a->M - 1) * a->lda + a->K) * 2ull < 0x7fffffffull &&
+                        (wk ? ((unsigned long long)(k_valid - 1) * a->ldw + a->N)
+                            : ((unsigned long long)(a->N - 1) * a->ldw + a->K)) * 2ull < 0x7fffffffull;
+    static const int dma_waves = [] { const char* e = getenv("STDIFF_GEMM_DMA128_WAVES"); return e && atoi(e) == 4 ? 4 : 8; }();
+    if (dma128 && wk && dma_waves == 8)
+        hipLaunchKernelGGL((gemm128d_kernel<true, 8>), grid, dim3(512), 0, (hipStream_t)stream, p);
+    else if (dma128 && wk)
+        hipLaunchKernelGGL((gemm128d_kernel<true, 4>), grid, block, 0, (hipStream_t)stream, p);
+    else if (dma128 && dma_waves == 8)
+        hipLaunchKernelGGL((gemm128d_kernel<false, 8>), grid, dim3(512), 0, (hipStream_t)stream, p);
+    else if (dma128)
+        hipLaunchKernelGGL((gemm128d_kernel<false, 4>), grid, block, 0, (hipStream_t)stream, p);
+    else if (!bf)
         STDIFF_LAUNCH128(float);
     else if (tile == 1)
         STDIFF_LAUNCH128(bf16_t);

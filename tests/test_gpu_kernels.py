@@ -285,6 +285,56 @@ def test_gemm_256_kernel_all_epilogues(ops, L, M, N, K, variant, gemm_knobs):
 
 
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
+def test_gemm_128_dma_variant_equals_register_staged(ops, L, gemm_knobs, dt):
+    """gemm128d_kernel (the 128 x 128 tile with LDS-DMA staging and eight waves, STDIFF_GEMM_DMA128) against gemm_nt_kernel
+    (register staging, four waves): the same fragments into the same MFMAs in the same order, so the same bits -- ragged M / N edges, W
+    row-major and K-major (with a K that is not a multiple of the slab: k_valid < K), 1 ... 64 K-slabs (prologue, steady
+    state and tail of the four-buffer ring), split-K through a workspace, and every epilogue kind."""
+    L.lib(dt == "fp16")
+    ws = torch.empty(64 << 20, device=DEV, dtype=torch.uint8)
+
+    def both(fn):
+        outs = []
+        for dma in ("0", "2"):                 # 2: K-major W as well (the default, 1, covers row-major W only)
+            gemm_knobs(STDIFF_GEMM_TILE="1", STDIFF_GEMM_DEPTH="3", STDIFF_GEMM_DMA128=dma)
+            outs.append(fn())
+        for x, y in zip(*outs):
+            assert torch.equal(x.view(torch.int32 if x.dtype == torch.float32 else torch.int16),
+                               y.view(torch.int32 if y.dtype == torch.float32 else torch.int16))
+        return outs[0]
+
+    for (M, N, K) in [(512, 1024, 1024), (96, 72, 64), (300, 520, 192), (512, 128, 4096), (130, 1000, 320)]:
+        A, W, b = to_dt(rnd(M, K, seed=51), dt), to_dt(rnd(N, K, seed=52, scale=K ** -0.5), dt), rnd(N, seed=53).to(DEV)
+        ref = A.float() @ W.float().T + b
+        got = both(lambda: [ops.gemm(A, W, b, out_dtype=torch.float32, workspace=ws), ops.gemm(A, W, b, workspace=ws),
+                            ops.gemm(A, W, None, out_dtype=torch.float32, epi=L.EPI_SILU),
+                            ops.gemm(A, W, b, epi=L.EPI_GELU, workspace=ws)])
+        assert relerr(got[0], ref) < 3e-5
+        res, gate = rnd(M, N, seed=54).to(DEV), to_dt(rnd(M, 2 * N, seed=55), dt)
+
+        def side():
+            h = torch.full((M, N), float("nan"), device=DEV)
+            v = torch.full((M, N), float("nan"), device=DEV, dtype=A.dtype)
+            ops.gemm(A, W, b, out=h, epi=L.EPI_GATE_RES, gate=gate[:, N:], res=res, out2=v, workspace=ws)
+            acc = res.clone()
+            ops.gemm(A, W, b, out=acc, epi=L.EPI_ACCUM, workspace=ws)
+            o1 = torch.empty(M, N, device=DEV, dtype=A.dtype)
+            o2 = torch.empty(M, N, device=DEV, dtype=A.dtype)
+            ops.gemm(A, W, b, out=o1, epi=L.EPI_GELU_SAVE, out2=o2)
+            return [h, v, acc, ops.gemm(A, W, b, out_dtype=torch.float32, epi=L.EPI_ADD, res=res), o1, o2]
+        both(side)
+    # W K-major: dX = dY W with W [out = K, in = N]; K = 200 output features (k_valid 200 of 256), and a GELU-backward epilogue
+    for (M, Kv, N) in [(512, 1024, 1024), (100, 200, 136), (512, 4096, 1024), (64, 72, 2048)]:
+        dY, Wk = to_dt(rnd(M, (Kv + 63) // 64 * 64, seed=61), dt), to_dt(rnd(Kv, N, seed=62, scale=Kv ** -0.5), dt)
+        dY[:, Kv:] = 0
+        upre = to_dt(rnd(M, N, seed=63), dt)
+        got = both(lambda: [ops.gemm(dY, Wk, None, out_dtype=torch.float32, w_kmajor=True, workspace=ws),
+                            ops.gemm(dY, Wk, None, w_kmajor=True, workspace=ws),
+                            ops.gemm(dY, Wk, None, w_kmajor=True, epi=L.EPI_GELU_BWD, gate=upre)])
+        assert relerr(got[0], dY[:, :Kv].float() @ Wk.float()) < 3e-5
+
+
+@pytest.mark.parametrize("dt", ["bf16", "fp16"])
 def test_gemm_192t_equals_256q(ops, L, gemm_knobs, dt):
     """gemm192t_kernel (192 x 256 tile, the previous tile leaves during the next tile's K loop; opt-in with
     STDIFF_GEMM_TILE=5, profiles/notes/r03_gemm192t.md) against gemm256q_kernel: the same bits -- ragged M / N edges, with
